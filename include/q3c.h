@@ -1,0 +1,128 @@
+/* q3c - C ABI of the MI355X (gfx950) Qwen3-TTS 12 Hz speech-tokenizer decode library.
+ *
+ * The reference repository (mindvridge/Qwen3-TTS) has no FFI of its own for this path: the decode is
+ * Python inside the `qwen-tts` dependency and is reached implicitly at the end of
+ * `Qwen3TTSModel.generate_voice_clone` (reference server.py:245-251) and `generate_custom_voice`
+ * (reference models.py:96-101).  Each entry point below names the Python-level operation it stands in
+ * for; the sibling lines (`sib` = transformers/models/qwen3_omni_moe/modeling_qwen3_omni_moe.py,
+ * `mimi` = transformers/models/mimi/modeling_mimi.py) give the arithmetic it must reproduce.
+ *
+ * Conventions
+ *  - plain C: no C++ types, no exceptions.  Every function returns 0 on success or a negative q3c_status;
+ *    q3c_last_error(ctx) returns a message owned by the context (valid until the next call on it).
+ *  - device pointers are owned by the caller; the library never frees or reallocates them.  The library
+ *    owns only what q3c_finalize() allocated (repacked weights, RoPE tables) and frees it in q3c_destroy().
+ *  - launch functions take a hipStream_t (passed as void*), are asynchronous and never synchronise.
+ *  - one context per (process, device); calls on one context must not overlap; distinct contexts are
+ *    independent.
+ *  - activations are channels-last: [batch][time][channel].
+ */
+#ifndef Q3C_H
+#define Q3C_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define Q3C_MAX_STAGES 8
+
+typedef enum q3c_status {
+    Q3C_OK = 0,
+    Q3C_ERR_INVALID_ARGUMENT = -1,   /* bad size / pointer / configuration */
+    Q3C_ERR_WEIGHT = -2,             /* unknown name, wrong shape, missing tensor */
+    Q3C_ERR_STATE = -3,              /* call order (e.g. forward before finalize) */
+    Q3C_ERR_WORKSPACE = -4,          /* workspace too small */
+    Q3C_ERR_HIP = -5,                /* a HIP runtime call failed */
+    Q3C_ERR_CODES = -6,              /* a code index was outside [0, codebook_size) */
+    Q3C_ERR_UNSUPPORTED = -7         /* shape outside what the kernels cover */
+} q3c_status;
+
+typedef enum q3c_precision { Q3C_PRECISION_F32 = 0, Q3C_PRECISION_BF16 = 1 } q3c_precision;
+typedef enum q3c_frontend { Q3C_FRONTEND_SPLIT_RVQ = 0, Q3C_FRONTEND_MEAN_EMBEDDING = 1 } q3c_frontend;
+
+/* Mirrors the decoder_config the Python side loads (sizes of sib configuration :538-554 plus the split-RVQ
+ * front end of mimi :1084-1097).  struct_size must be sizeof(q3c_config). */
+typedef struct q3c_config {
+    int32_t struct_size;
+    int32_t frontend;                 /* q3c_frontend */
+    int32_t precision;                /* q3c_precision: storage + MFMA operand type of the whole decode */
+    int32_t codebook_size, num_quantizers, num_semantic_quantizers, codebook_dim, rvq_out_dim, pre_conv_kernel;
+    int32_t latent_dim, hidden_size, io_proj;
+    int32_t num_attention_heads, num_key_value_heads, head_dim, intermediate_size, num_hidden_layers, sliding_window;
+    int32_t num_upsampling_ratios; int32_t upsampling_ratios[Q3C_MAX_STAGES];
+    int32_t num_upsample_rates;    int32_t upsample_rates[Q3C_MAX_STAGES];
+    int32_t decoder_dim;
+    int32_t num_dilations;         int32_t dilations[Q3C_MAX_STAGES];
+    int32_t max_positions;            /* longest single forward, in frames */
+    float rvq_eps, rms_norm_eps, convnext_eps, snake_eps;
+} q3c_config;
+
+typedef struct q3c_ctx q3c_ctx;
+
+/* Stages whose output q3c_set_tap can capture (as fp32, channels-last). */
+typedef enum q3c_stage {
+    Q3C_STAGE_RVQ_OUT = 0,          /* [B,T,rvq_out_dim]  after the output_proj of both groups (split_rvq) */
+    Q3C_STAGE_TRANSFORMER_IN = 1,   /* [B,T,latent_dim]   after pre_conv / the mean embedding */
+    Q3C_STAGE_TRANSFORMER_OUT = 2,  /* [B,T,latent_dim] */
+    Q3C_STAGE_UPSAMPLE0 = 3,        /* + i: output of upsample stage i */
+    Q3C_STAGE_CONV_IN = 16,         /* [B,4T,decoder_dim] WITH the first block's SnakeBeta already applied */
+    Q3C_STAGE_BLOCK0 = 17           /* + i: output of decoder block i WITH the next SnakeBeta already applied */
+} q3c_stage;
+
+/* -- lifetime -------------------------------------------------------------------------------------------
+ * Stands in for constructing the decoder module inside Qwen3TTSModel.from_pretrained (reference models.py:43-48). */
+int q3c_create(const q3c_config* cfg, q3c_ctx** out);
+void q3c_destroy(q3c_ctx* ctx);
+const char* q3c_last_error(const q3c_ctx* ctx);
+const char* q3c_version(void);
+
+/* -- weights ---------------------------------------------------------------------------------------------
+ * Stands in for load_state_dict: one call per tensor, HOST fp32 data in the PyTorch layout, names as in the
+ * sibling's state dict (e.g. "decoder.1.block.2.conv1.conv.weight"); q3c_finalize() checks every tensor the
+ * configuration needs is present with the right shape, repacks ([tap][out][in], transposed-conv phase split,
+ * codebook = embed_sum / clamp(cluster_usage, eps) with an IEEE divide - mimi :980-983) and uploads. */
+int q3c_load_weight(q3c_ctx* ctx, const char* name, const float* host_data, const int64_t* shape, int32_t ndim);
+int q3c_finalize(q3c_ctx* ctx);
+
+/* -- the hot path ----------------------------------------------------------------------------------------
+ * q3c_forward = Code2Wav.forward (sib :3672-3684): codes [B][Q][T] int64 on the device ->
+ * wav [B][T*total_upsample - trim] fp32 on the device, clamped to [-1, 1].  workspace is caller-owned device
+ * memory of at least q3c_workspace_bytes(B, T) bytes, 256-byte aligned. */
+int q3c_workspace_bytes(q3c_ctx* ctx, int32_t batch, int32_t frames, size_t* bytes);
+int q3c_output_length(const q3c_ctx* ctx, int32_t frames, int64_t* samples);
+int q3c_forward(q3c_ctx* ctx, const int64_t* codes_dev, int32_t batch, int32_t frames, float* wav_dev,
+                void* workspace_dev, size_t workspace_bytes, void* hip_stream);
+
+/* RVQ gather-and-sum alone (mimi :1070-1077 per group, bit-exact fp32): codes [B][Q][T] ->
+ * sums [B][T][G][codebook_dim] with G = 1 (semantic) + 1 (acoustic, when num_quantizers > num_semantic). */
+int q3c_rvq_dequant_f32(q3c_ctx* ctx, const int64_t* codes_dev, int32_t batch, int32_t frames, float* sums_dev,
+                        void* hip_stream);
+
+/* Sticky device-side error word (out-of-range code index).  Synchronises the stream; returns Q3C_ERR_CODES if set
+ * and clears it.  Stands in for the IndexError torch's embedding raises. */
+int q3c_check_errors(q3c_ctx* ctx, void* hip_stream);
+
+/* Capture a stage output of the following q3c_forward calls as fp32 into caller memory (NULL removes the tap). */
+int q3c_set_tap(q3c_ctx* ctx, int32_t stage, float* dev_buffer, size_t capacity_elements);
+
+/* -- single operators (host weights in the PyTorch layout are repacked and uploaded per call: meant for
+ *    operator-level parity tests and integration bring-up, not for the serving loop; they synchronise) ------
+ * x / y are DEVICE fp32, channels-last.  precision picks the MFMA operand type as in q3c_config. */
+/* CausalConvNet (sib :3180-3213), groups = 1: x [B][L][Cin] -> y [B][L][Cout]; weight [Cout][Cin][k]. */
+int q3c_causal_conv1d(const float* x_dev, int32_t batch, int32_t length, int32_t cin, int32_t cout, int32_t k, int32_t dilation,
+                      const float* weight_host, const float* bias_host, float* y_dev, int32_t precision, void* hip_stream);
+/* CausalTransConvNet (sib :3216-3228), k == stride or k == 2*stride: x [B][L][Cin] -> y [B][Lout][Cout];
+ * weight [Cin][Cout][k]; Lout = (L-1)*stride - k + 2*stride. */
+int q3c_causal_tconv1d(const float* x_dev, int32_t batch, int32_t length, int32_t cin, int32_t cout, int32_t k, int32_t stride,
+                       const float* weight_host, const float* bias_host, float* y_dev, int32_t precision, void* hip_stream);
+/* SnakeBeta (sib :3566-3580): y = x + 1/(exp(beta)+eps) * sin(x*exp(alpha))^2, x [rows][C]. */
+int q3c_snake_beta(const float* x_dev, int64_t rows, int32_t channels, const float* alpha_host, const float* beta_host,
+                   float eps, float* y_dev, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* Q3C_H */

@@ -1,0 +1,85 @@
+// Shared device helpers and the internal launcher interface of the gfx950 decode library.
+// Activations are channels-last [batch, time, channel]; weights are [tap][out][in] with `in` contiguous.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define Q3_WAVE 64
+
+enum Q3Act : int {
+    Q3_ACT_NONE = 0,
+    Q3_ACT_GELU = 1,    // exact erf GELU
+    Q3_ACT_SNAKE = 2,   // x + invb * sin(a x)^2 with per-output-channel (a, invb)
+    Q3_ACT_SWIGLU = 3,  // adjacent 32-column tiles hold (gate, up); out = silu(gate) * up, N_out = N / 2
+};
+
+// out[b, m, n] = post( R[b, m, n] + scale[n] * act( bias[n] + sum_tap sum_k pro(X[b, m + off0 + tap*off_step, k]) * W[tap][n][k] ) )
+// rows of X outside [0, L_in) read as zero (before and after `pro`, since pro(0) = 0 for snake).
+struct ConvGemmArgs {
+    const void* X;  long long x_batch_stride; int ldx; int L_in;
+    const void* W;                       // [taps][N][K]
+    const float* bias;                   // [N] or null
+    void* Y;        long long y_batch_stride; int ldy;
+    const void* R;  long long r_batch_stride; int ldr;   // residual, element type = output type, or null
+    int B, M, N, K;
+    int taps, off0, off_step;
+    const float* pro_a; const float* pro_invb;           // [K] snake on the input, or null
+    int act;
+    const float* epi_a; const float* epi_invb;           // [N] for Q3_ACT_SNAKE
+    const float* scale;                                  // [N_out] or null
+    const float* post_a; const float* post_invb;         // [N_out] snake after the residual add, or null
+};
+
+enum Q3Dtype : int { Q3_F32 = 0, Q3_BF16 = 1 };
+
+// ---- launchers (each returns hipError_t of the launch) -------------------------------------------
+hipError_t q3_launch_convgemm(const ConvGemmArgs& a, int in_dtype, int out_dtype, hipStream_t s);
+
+hipError_t q3_launch_rvq_gather_sum(const long long* codes, int B, int Q, int T, int bins, int D,
+                                    const float* const* tables_dev /*[Q] device array of table pointers*/,
+                                    const int* group_start_dev /*[G+1] first codebook of each group*/, int G,
+                                    float* out /*[B,T,G,D]*/, int* err_flag, hipStream_t s);
+hipError_t q3_launch_mean_embedding(const long long* codes, int B, int Q, int T, int bins, int H,
+                                    const float* table, void* out, int out_dtype, int* err_flag, hipStream_t s);
+hipError_t q3_launch_rmsnorm(const void* x, const float* w, void* y, long long rows, int H, float eps, int dtype, hipStream_t s);
+hipError_t q3_launch_dwconv_ln(const void* x, const float* w /*[C][7]*/, const float* b, const float* lnw, const float* lnb,
+                               void* y, int B, int L, int C, int k, float eps, int dtype, hipStream_t s);
+hipError_t q3_launch_swa_attention(const void* qkv, void* out, const float* cos_t, const float* sin_t, int B, int T,
+                                   int nh, int nkv, int d, int window, int dtype, hipStream_t s);
+hipError_t q3_launch_conv_out(const void* x, const float* w /*[k][C]*/, float bias, float* wav, int B, int L, int C, int k,
+                              int dtype, hipStream_t s);
+hipError_t q3_launch_cast_to_f32(const void* x, float* y, long long n, int dtype, hipStream_t s);
+hipError_t q3_launch_cast_from_f32(const float* x, void* y, long long n, int dtype, hipStream_t s);
+hipError_t q3_launch_snake(const void* x, void* y, const float* a, const float* invb, long long rows, int C, int dtype, hipStream_t s);
+
+// ---- device helpers -------------------------------------------------------------------------------
+#ifdef __HIPCC__
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> { static constexpr int EPC = 4; };   // elements per 16-byte chunk
+template <> struct ElemTraits<bf16>  { static constexpr int EPC = 8; };
+
+__device__ __forceinline__ float q3_to_f32(float v) { return v; }
+__device__ __forceinline__ float q3_to_f32(bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T q3_from_f32(float v);
+template <> __device__ __forceinline__ float q3_from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 q3_from_f32<bf16>(float v) { return (bf16)v; }
+
+// Accurate sine for the fp32 path (parity bar 1e-3 after ~40 layers); the hardware v_sin for the bf16 path,
+// whose storage rounding (2^-9 relative) is far coarser than v_sin's error.
+template <typename T> __device__ __forceinline__ float q3_sin(float x);
+template <> __device__ __forceinline__ float q3_sin<float>(float x) { return sinf(x); }
+template <> __device__ __forceinline__ float q3_sin<bf16>(float x) { return __sinf(x); }
+
+template <typename T> __device__ __forceinline__ float q3_snake(float x, float a, float invb) {
+    float s = q3_sin<T>(x * a);
+    return x + invb * (s * s);
+}
+__device__ __forceinline__ float q3_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float q3_silu(float x) { return x / (1.0f + expf(-x)); }
+#endif

@@ -1,0 +1,331 @@
+// Multi-tap row-shifted GEMM on the gfx950 matrix cores: the one dense-contraction kernel of the decode.
+//
+//   out[b, m, n] = post( R[b,m,n] + scale[n] * act( bias[n] + sum_tap sum_k pro(X[b, m + off0 + tap*off_step, k]) * W[tap][n][k] ) )
+//
+// With channels-last activations every layer of the decoder is this form:
+//   causal Conv1d(k, dilation d)      taps = k, off0 = -(k-1)d, off_step = d
+//   ConvTranspose1d(k = 2s, stride s) taps = 2, off0 = 0, off_step = 1, N = s*Cout  (row q of [L-1, s*Cout] IS rows q*s .. q*s+s-1 of [.., Cout])
+//   ConvTranspose1d(k = s,  stride s) taps = 1, N = s*Cout
+//   Linear                            taps = 1
+// A block owns a BM x BN output tile.  Per K-chunk the (BM + halo) input rows are staged ONCE in LDS and
+// every tap reads them at a row offset, so the im2col matrix never exists.  Weight tiles are staged per
+// (K-chunk, tap) step; both operands are prefetched into registers one step ahead and land in the other
+// LDS buffer after the step's MFMAs (one barrier per step).  LDS rows are BKB bytes with a 16-byte-chunk
+// XOR swizzle so that the 16-lane groups of ds_read_b128 touch 16 distinct 16-byte slots.
+//
+// Element types: bf16 operands -> v_mfma_f32_32x32x16_bf16; fp32 operands -> v_mfma_f32_32x32x2_f32
+// (bit-exact fp32 FMA chains, used by the parity path).  Accumulation is fp32 in both.
+#include "common.h"
+
+namespace {
+
+template <int CPR> __device__ __forceinline__ int swz(int row, int c) {
+    if constexpr (CPR == 8) return c ^ ((row >> 1) & 7);
+    else return c ^ ((row >> 2) & 3);
+}
+
+template <typename TA> struct Mma;
+template <> struct Mma<bf16> {
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    // lane half h holds k = 4h .. 4h+3 of an 8-deep group for BOTH operands; MFMA j contracts k in {j, 4 + j}
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, b.x), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.y), __builtin_bit_cast(float, b.y), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.z), __builtin_bit_cast(float, b.z), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.w), __builtin_bit_cast(float, b.w), c, 0, 0, 0);
+    }
+};
+
+// snake on one 16-byte piece
+template <typename TA> __device__ __forceinline__ uint4 snake_piece(uint4 v, const float* a, const float* ib);
+template <> __device__ __forceinline__ uint4 snake_piece<float>(uint4 v, const float* a, const float* ib) {
+    float x0 = __builtin_bit_cast(float, v.x), x1 = __builtin_bit_cast(float, v.y);
+    float x2 = __builtin_bit_cast(float, v.z), x3 = __builtin_bit_cast(float, v.w);
+    x0 = q3_snake<float>(x0, a[0], ib[0]); x1 = q3_snake<float>(x1, a[1], ib[1]);
+    x2 = q3_snake<float>(x2, a[2], ib[2]); x3 = q3_snake<float>(x3, a[3], ib[3]);
+    return make_uint4(__builtin_bit_cast(unsigned, x0), __builtin_bit_cast(unsigned, x1),
+                      __builtin_bit_cast(unsigned, x2), __builtin_bit_cast(unsigned, x3));
+}
+template <> __device__ __forceinline__ uint4 snake_piece<bf16>(uint4 v, const float* a, const float* ib) {
+    bf16x8 h = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) h[e] = (bf16)q3_snake<bf16>((float)h[e], a[e], ib[e]);
+    return __builtin_bit_cast(uint4, h);
+}
+
+template <typename TA, typename TO, int WAVES_M, int WAVES_N, int WM, int WN, int BKB>
+__global__ void __launch_bounds__(256) convgemm_kernel(const ConvGemmArgs p) {
+    constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
+    constexpr int CPR = BKB / 16;                    // 16-byte chunks per LDS row
+    constexpr int EPC = ElemTraits<TA>::EPC;         // elements per chunk
+    constexpr int BK = CPR * EPC;                    // K elements per chunk row
+    constexpr int KG = BKB / 32;                     // fragment groups per step
+    constexpr int NTHR = 256;
+    constexpr int WITER = (BN * CPR + NTHR - 1) / NTHR;
+    constexpr int MAX_XPS = (BM * CPR + NTHR - 1) / NTHR;
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
+    static_assert(NTHR % CPR == 0, "column chunk of a thread is fixed");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    // 1-D tile index with the N tiles fastest: blocks that share an input tile are dispatched together
+    const int n_tiles = (p.N + BN - 1) / BN;
+    const int b = blockIdx.y;
+    const int n0 = (int)(blockIdx.x % n_tiles) * BN;
+    const int m0 = (int)(blockIdx.x / n_tiles) * BM;
+
+    const int halo = (p.taps - 1) * p.off_step;
+    const int HR = BM + halo;                        // staged input rows
+    const int xpieces = HR * CPR;
+    const int xi_total = (xpieces + NTHR - 1) / NTHR;
+    const int xps = (xi_total + p.taps - 1) / p.taps;   // pieces per thread per step (<= MAX_XPS, host-checked)
+
+    unsigned char* Xs0 = smem;
+    unsigned char* Ws0 = smem + 2 * (size_t)HR * BKB;
+
+    const TA* __restrict__ Xb = (const TA*)p.X + (long long)b * p.x_batch_stride;
+    const TA* __restrict__ Wg = (const TA*)p.W;
+    const int nkc = (p.K + BK - 1) / BK;
+    const int nsteps = nkc * p.taps;
+    const int my_c = tid % CPR;                      // column chunk of every piece this thread stages
+    const bool has_pro = p.pro_a != nullptr;
+
+    float pa[EPC], pib[EPC];
+    auto load_pro = [&](int kc) {
+        if (has_pro) {
+            int k = kc * BK + my_c * EPC;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                bool ok = (k + e) < p.K;
+                pa[e] = ok ? p.pro_a[k + e] : 0.f;
+                pib[e] = ok ? p.pro_invb[k + e] : 0.f;
+            }
+        }
+    };
+    auto x_load = [&](int id, int kc) -> uint4 {
+        int row = id / CPR;
+        int grow = m0 + p.off0 + row;
+        int kel = kc * BK + my_c * EPC;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (id < xpieces && grow >= 0 && grow < p.L_in && kel < p.K)
+            v = *(const uint4*)(Xb + (long long)grow * p.ldx + kel);
+        return v;
+    };
+    auto x_store = [&](unsigned char* xs, int id, uint4 v) {
+        if (id < xpieces) {
+            int row = id / CPR;
+            if (has_pro) v = snake_piece<TA>(v, pa, pib);
+            *(uint4*)(xs + (size_t)row * BKB + swz<CPR>(row, my_c) * 16) = v;
+        }
+    };
+    auto w_load = [&](int id, int kc, int tap) -> uint4 {
+        int row = id / CPR, c = id % CPR;
+        int n = n0 + row;
+        int kel = kc * BK + c * EPC;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (id < BN * CPR && n < p.N && kel < p.K)
+            v = *(const uint4*)(Wg + ((long long)tap * p.N + n) * p.K + kel);
+        return v;
+    };
+    auto w_store = [&](unsigned char* ws, int id, uint4 v) {
+        if (id < BN * CPR) {
+            int row = id / CPR, c = id % CPR;
+            *(uint4*)(ws + (size_t)row * BKB + swz<CPR>(row, c) * 16) = v;
+        }
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- prologue: whole X tile of chunk 0, W tile of step 0 -------------------------------------
+    load_pro(0);
+    for (int it = 0; it < xi_total; ++it) {
+        int id = tid + it * NTHR;
+        x_store(Xs0, id, x_load(id, 0));
+    }
+    load_pro(1);
+#pragma unroll
+    for (int it = 0; it < WITER; ++it) {
+        int id = tid + it * NTHR;
+        w_store(Ws0, id, w_load(id, 0, 0));
+    }
+    __syncthreads();
+
+    int kc = 0, tap = 0;
+    for (int step = 0; step < nsteps; ++step) {
+        int ntap = tap + 1, nkc_ = kc;
+        if (ntap == p.taps) { ntap = 0; nkc_ = kc + 1; }
+        const bool has_next = (step + 1) < nsteps;
+        const bool x_next = (kc + 1) < nkc;
+
+        // issue next step's global loads
+        uint4 wreg[WITER];
+        uint4 xreg[MAX_XPS];
+        if (has_next) {
+#pragma unroll
+            for (int it = 0; it < WITER; ++it) wreg[it] = w_load(tid + it * NTHR, nkc_, ntap);
+        }
+        if (x_next) {
+#pragma unroll
+            for (int i = 0; i < MAX_XPS; ++i) {
+                int it = tap * xps + i;
+                xreg[i] = (i < xps && it < xi_total) ? x_load(tid + it * NTHR, kc + 1) : make_uint4(0, 0, 0, 0);
+            }
+        }
+
+        // MFMAs of this step
+        const unsigned char* xs = Xs0 + (size_t)(kc & 1) * HR * BKB;
+        const unsigned char* ws = Ws0 + (size_t)(step & 1) * BN * BKB;
+        const int arow0 = wm * 32 * WM + (lane & 31) + tap * p.off_step;
+        const int brow0 = wn * 32 * WN + (lane & 31);
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) {
+            const int c = kg * 2 + (lane >> 5);
+            uint4 af[WM], bfr[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+                int row = arow0 + i * 32;
+                af[i] = *(const uint4*)(xs + (size_t)row * BKB + swz<CPR>(row, c) * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                int row = brow0 + j * 32;
+                bfr[j] = *(const uint4*)(ws + (size_t)row * BKB + swz<CPR>(row, c) * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) Mma<TA>::run(af[i], bfr[j], acc[i][j]);
+        }
+
+        // land the prefetched tiles in the other buffers
+        if (has_next) {
+            unsigned char* wsn = Ws0 + (size_t)((step + 1) & 1) * BN * BKB;
+#pragma unroll
+            for (int it = 0; it < WITER; ++it) w_store(wsn, tid + it * NTHR, wreg[it]);
+        }
+        if (x_next) {
+            unsigned char* xsn = Xs0 + (size_t)((kc + 1) & 1) * HR * BKB;
+#pragma unroll
+            for (int i = 0; i < MAX_XPS; ++i) {
+                int it = tap * xps + i;
+                if (i < xps && it < xi_total) x_store(xsn, tid + it * NTHR, xreg[i]);
+            }
+        }
+        __syncthreads();
+        if (ntap == 0) load_pro(nkc_ + 1);   // parameters for the tile staged during the next chunk's steps
+        tap = ntap; kc = nkc_;
+    }
+
+    // ---- epilogue ----------------------------------------------------------------------------------
+    TO* __restrict__ Yb = (TO*)p.Y + (long long)b * p.y_batch_stride;
+    const TO* __restrict__ Rb = p.R ? (const TO*)p.R + (long long)b * p.r_batch_stride : nullptr;
+    const int mbase = m0 + wm * 32 * WM + 4 * (lane >> 5);
+
+    if (p.act == Q3_ACT_SWIGLU) {
+        if constexpr (WN % 2 == 0) {
+            const int n_out_total = p.N / 2;
+#pragma unroll
+            for (int j = 0; j < WN; j += 2) {
+                const int tile = (n0 >> 5) + wn * WN + j;          // even: gate tile, tile + 1: up tile
+                const int n = (tile >> 1) * 32 + (lane & 31);
+                if (n >= n_out_total) continue;
+                const float sc = p.scale ? p.scale[n] : 1.f;
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int m = mbase + i * 32 + (r & 3) + 8 * (r >> 2);
+                        if (m >= p.M) continue;
+                        float v = q3_silu(acc[i][j][r]) * acc[i][j + 1][r] * sc;
+                        if (Rb) v += q3_to_f32(Rb[(long long)m * p.ldr + n]);
+                        Yb[(long long)m * p.ldy + n] = q3_from_f32<TO>(v);
+                    }
+            }
+        }
+        return;
+    }
+
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int n = n0 + wn * 32 * WN + j * 32 + (lane & 31);
+        if (n >= p.N) continue;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+        const float sc = p.scale ? p.scale[n] : 1.f;
+        float ea = 0.f, eib = 0.f, qa = 0.f, qib = 0.f;
+        if (p.act == Q3_ACT_SNAKE) { ea = p.epi_a[n]; eib = p.epi_invb[n]; }
+        const bool has_post = p.post_a != nullptr;
+        if (has_post) { qa = p.post_a[n]; qib = p.post_invb[n]; }
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = mbase + i * 32 + (r & 3) + 8 * (r >> 2);
+                if (m >= p.M) continue;
+                float v = acc[i][j][r] + bias;
+                if (p.act == Q3_ACT_GELU) v = q3_gelu(v);
+                else if (p.act == Q3_ACT_SNAKE) v = q3_snake<TO>(v, ea, eib);
+                v *= sc;
+                if (Rb) v += q3_to_f32(Rb[(long long)m * p.ldr + n]);
+                if (has_post) v = q3_snake<TO>(v, qa, qib);
+                Yb[(long long)m * p.ldy + n] = q3_from_f32<TO>(v);
+            }
+    }
+}
+
+template <typename TA, typename TO, int WAVES_M, int WAVES_N, int WM, int WN, int BKB>
+hipError_t launch_cfg(const ConvGemmArgs& a, hipStream_t s) {
+    constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
+    constexpr int CPR = BKB / 16;
+    const int halo = (a.taps - 1) * a.off_step;
+    const int HR = BM + halo;
+    const int xi_total = (HR * CPR + 255) / 256;
+    const int xps = (xi_total + a.taps - 1) / a.taps;
+    if (xps > (BM * CPR + 255) / 256) return hipErrorInvalidValue;      // halo too large for the staged-slice scheme
+    size_t lds = 2 * (size_t)HR * BKB + 2 * (size_t)BN * BKB;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    auto kern = convgemm_kernel<TA, TO, WAVES_M, WAVES_N, WM, WN, BKB>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    const long long tiles = (long long)((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM);
+    if (tiles > 0x7fffffffLL || a.B > 65535) return hipErrorInvalidValue;
+    dim3 grid((unsigned)tiles, a.B, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+template <typename TA, typename TO>
+hipError_t launch_typed(const ConvGemmArgs& a, hipStream_t s) {
+    const bool wide_k = ((size_t)a.K * sizeof(TA)) % 128 == 0;
+    const bool use_96 = (a.act != Q3_ACT_SWIGLU) && (a.N % 128 != 0) && (a.N % 96 == 0) && a.N < 512;
+    if (use_96) return launch_cfg<TA, TO, 4, 1, 2, 3, 64>(a, s);
+    if (wide_k) return launch_cfg<TA, TO, 2, 2, 2, 2, 128>(a, s);
+    return launch_cfg<TA, TO, 2, 2, 2, 2, 64>(a, s);
+}
+
+}  // namespace
+
+hipError_t q3_launch_convgemm(const ConvGemmArgs& a, int in_dtype, int out_dtype, hipStream_t s) {
+    if (a.M <= 0 || a.B <= 0) return hipSuccess;
+    const int epc_in = in_dtype == Q3_BF16 ? 8 : 4;
+    if (a.K % epc_in || a.ldx % epc_in || a.x_batch_stride % epc_in || a.taps < 1 || a.off_step < 0)
+        return hipErrorInvalidValue;
+    if (((uintptr_t)a.X | (uintptr_t)a.W) & 15) return hipErrorInvalidValue;
+    if (in_dtype == Q3_F32 && out_dtype == Q3_F32) return launch_typed<float, float>(a, s);
+    if (in_dtype == Q3_BF16 && out_dtype == Q3_BF16) return launch_typed<bf16, bf16>(a, s);
+    if (in_dtype == Q3_F32 && out_dtype == Q3_BF16) return launch_typed<float, bf16>(a, s);
+    return hipErrorInvalidValue;
+}

@@ -1,0 +1,745 @@
+// Host side of the q3c C ABI: context, weight repacking, and the launch sequence of one decode forward.
+// Declarations and their reference citations are in include/q3c.h.
+#include "../../include/q3c.h"
+#include "common.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct HostTensor { std::vector<int64_t> shape; std::vector<float> data; };
+
+struct GemmW {            // one packed contraction layer
+    void* w = nullptr;    // [taps][N][K], element type in_dtype
+    float* bias = nullptr;
+    int taps = 1, N = 0, K = 0, off0 = 0, off_step = 0, in_dtype = Q3_F32;
+};
+struct Snake { float* a = nullptr; float* invb = nullptr; int C = 0; };
+
+struct Layer { float* ln1; float* ln2; GemmW qkv, o, gu, down; float* ls_attn; float* ls_mlp; };
+struct UpStage { GemmW tconv; int f; float *dw_w, *dw_b, *ln_w, *ln_b; GemmW pw1, pw2; float* gamma; };
+struct Unit { Snake a1, a2; GemmW c1, c2; };
+struct Block { Snake head; GemmW tconv; int rate; std::vector<Unit> units; };
+
+uint16_t f32_to_bf16(float f) {
+    uint32_t u; std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+}  // namespace
+
+struct q3c_ctx {
+    q3c_config cfg{};
+    int dtype = Q3_F32;
+    mutable std::string err;
+    std::map<std::string, HostTensor> staged;
+    bool finalized = false;
+    std::vector<void*> allocs;
+
+    // front end
+    int G = 0;
+    std::vector<float*> tables;
+    float** tables_dev = nullptr;
+    int* group_start_dev = nullptr;
+    float* emb_table = nullptr;
+    GemmW rvq_proj, pre_conv, in_proj, out_proj;
+    // transformer
+    std::vector<Layer> layers;
+    float* final_norm = nullptr;
+    float *cos_t = nullptr, *sin_t = nullptr;
+    // conv decoder
+    std::vector<UpStage> ups;
+    GemmW conv_in;
+    std::vector<Block> blocks;
+    Snake final_snake;
+    float* out_w = nullptr; float out_b = 0.f; int out_k = 0;
+
+    int* err_flag = nullptr;
+    std::map<int, std::pair<float*, size_t>> taps;
+
+    int total_upsample = 1, trim = 0;
+};
+
+namespace {
+
+int fail(const q3c_ctx* c, int code, const std::string& msg) { if (c) c->err = msg; return code; }
+
+#define HIPCHK(ctx, expr)                                                                              \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess)                                                                          \
+            return fail(ctx, Q3C_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));          \
+    } while (0)
+
+size_t esize(int dtype) { return dtype == Q3_BF16 ? 2 : 4; }
+size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+// ---- uploads ------------------------------------------------------------------------------------------
+int dev_alloc(q3c_ctx* c, size_t bytes, void** out) {
+    void* p = nullptr;
+    HIPCHK(c, hipMalloc(&p, bytes ? bytes : 16));
+    c->allocs.push_back(p);
+    *out = p;
+    return 0;
+}
+int upload_f32(q3c_ctx* c, const std::vector<float>& v, float** out) {
+    void* p; int r = dev_alloc(c, v.size() * 4, &p); if (r) return r;
+    HIPCHK(c, hipMemcpy(p, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+    *out = (float*)p;
+    return 0;
+}
+int upload_typed(q3c_ctx* c, const std::vector<float>& v, int dtype, void** out) {
+    if (dtype == Q3_F32) { float* p; int r = upload_f32(c, v, &p); *out = p; return r; }
+    std::vector<uint16_t> h(v.size());
+    for (size_t i = 0; i < v.size(); ++i) h[i] = f32_to_bf16(v[i]);
+    void* p; int r = dev_alloc(c, h.size() * 2, &p); if (r) return r;
+    HIPCHK(c, hipMemcpy(p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    *out = p;
+    return 0;
+}
+
+// ---- weight lookup ------------------------------------------------------------------------------------
+const HostTensor* find(q3c_ctx* c, const std::string& name, std::initializer_list<int64_t> shape, int* rc) {
+    auto it = c->staged.find(name);
+    if (it == c->staged.end()) { *rc = fail(c, Q3C_ERR_WEIGHT, "missing weight " + name); return nullptr; }
+    std::vector<int64_t> want(shape);
+    if (it->second.shape != want) {
+        std::string s = "weight " + name + " has shape [";
+        for (auto d : it->second.shape) s += std::to_string(d) + ",";
+        s += "], expected [";
+        for (auto d : want) s += std::to_string(d) + ",";
+        *rc = fail(c, Q3C_ERR_WEIGHT, s + "]");
+        return nullptr;
+    }
+    return &it->second;
+}
+#define GETW(var, name, ...)                                   \
+    const HostTensor* var = find(c, name, {__VA_ARGS__}, &rc); \
+    if (!var) return rc
+
+// causal Conv1d weight [Cout][Cin][k] -> [k][Cout][Cin]
+int pack_conv(q3c_ctx* c, const std::string& prefix, int cout, int cin, int k, int dil, int dtype, GemmW* g, bool has_bias = true) {
+    int rc = 0;
+    GETW(w, prefix + ".weight", cout, cin, k);
+    std::vector<float> p((size_t)k * cout * cin);
+    for (int n = 0; n < cout; ++n)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int t = 0; t < k; ++t) p[((size_t)t * cout + n) * cin + ci] = w->data[((size_t)n * cin + ci) * k + t];
+    g->taps = k; g->N = cout; g->K = cin; g->off0 = -(k - 1) * dil; g->off_step = dil; g->in_dtype = dtype;
+    if ((rc = upload_typed(c, p, dtype, &g->w))) return rc;
+    if (has_bias) {
+        GETW(b, prefix + ".bias", cout);
+        if ((rc = upload_f32(c, b->data, &g->bias))) return rc;
+    }
+    return 0;
+}
+// Linear weight [out][in] (+ optional bias)
+int pack_linear(q3c_ctx* c, const std::string& wname, const std::string& bname, int out, int in, int dtype, GemmW* g) {
+    int rc = 0;
+    GETW(w, wname, out, in);
+    g->taps = 1; g->N = out; g->K = in; g->off0 = 0; g->off_step = 0; g->in_dtype = dtype;
+    if ((rc = upload_typed(c, w->data, dtype, &g->w))) return rc;
+    if (!bname.empty()) {
+        GETW(b, bname, out);
+        if ((rc = upload_f32(c, b->data, &g->bias))) return rc;
+    }
+    return 0;
+}
+// ConvTranspose1d weight [Cin][Cout][k], stride s, k == s or k == 2s, as a GEMM over N = s*Cout columns:
+//   k == 2s: y[q*s+p] = x[q] . w[:, :, p+s] + x[q+1] . w[:, :, p]      (after the two-sided trim of k - s)
+//   k ==  s: y[q*s+p] = x[q] . w[:, :, p]
+int pack_tconv_host(q3c_ctx* c, const float* w, const float* b, int cin, int cout, int k, int s, int dtype, GemmW* g) {
+    if (k != s && k != 2 * s) return fail(c, Q3C_ERR_UNSUPPORTED, "transposed conv needs kernel == stride or 2*stride");
+    const int taps = k / s, N = s * cout;
+    std::vector<float> p((size_t)taps * N * cin);
+    for (int t = 0; t < taps; ++t)
+        for (int ph = 0; ph < s; ++ph)
+            for (int co = 0; co < cout; ++co)
+                for (int ci = 0; ci < cin; ++ci) {
+                    int kk = (taps == 2) ? (t == 0 ? ph + s : ph) : ph;
+                    p[((size_t)t * N + ph * cout + co) * cin + ci] = w[((size_t)ci * cout + co) * k + kk];
+                }
+    g->taps = taps; g->N = N; g->K = cin; g->off0 = 0; g->off_step = 1; g->in_dtype = dtype;
+    int rc;
+    if ((rc = upload_typed(c, p, dtype, &g->w))) return rc;
+    if (b) {
+        std::vector<float> bb((size_t)N);
+        for (int ph = 0; ph < s; ++ph)
+            for (int co = 0; co < cout; ++co) bb[(size_t)ph * cout + co] = b[co];
+        if ((rc = upload_f32(c, bb, &g->bias))) return rc;
+    }
+    return 0;
+}
+int pack_tconv(q3c_ctx* c, const std::string& prefix, int cin, int cout, int k, int s, int dtype, GemmW* g) {
+    int rc = 0;
+    GETW(w, prefix + ".weight", cin, cout, k);
+    GETW(b, prefix + ".bias", cout);
+    return pack_tconv_host(c, w->data.data(), b->data.data(), cin, cout, k, s, dtype, g);
+}
+int pack_snake_host(q3c_ctx* c, const float* alpha, const float* beta, int C, float eps, Snake* s) {
+    std::vector<float> va(C), vb(C);
+    for (int i = 0; i < C; ++i) { va[i] = expf(alpha[i]); vb[i] = 1.0f / (expf(beta[i]) + eps); }
+    s->C = C;
+    int rc;
+    if ((rc = upload_f32(c, va, &s->a))) return rc;
+    return upload_f32(c, vb, &s->invb);
+}
+int pack_snake(q3c_ctx* c, const std::string& prefix, int C, Snake* s) {
+    int rc = 0;
+    GETW(a, prefix + "alpha", C);
+    GETW(b, prefix + "beta", C);
+    return pack_snake_host(c, a->data.data(), b->data.data(), C, c->cfg.snake_eps, s);
+}
+int pack_vec(q3c_ctx* c, const std::string& name, int n, float** out) {
+    int rc = 0;
+    GETW(v, name, n);
+    return upload_f32(c, v->data, out);
+}
+
+// ---- one convgemm launch --------------------------------------------------------------------------------
+struct GemmOpts {
+    const Snake* pro = nullptr;
+    int act = Q3_ACT_NONE;
+    const Snake* epi = nullptr;
+    const float* scale = nullptr;
+    const void* R = nullptr;
+    const Snake* post = nullptr;
+};
+
+// X [B][L_in][K] contiguous -> Y [B][M][N_out] contiguous (N_out = N, or N/2 for SwiGLU); R like Y.
+int gemm(q3c_ctx* c, const GemmW& g, const void* X, int B, int L_in, void* Y, int M, int out_dtype, const GemmOpts& o,
+         hipStream_t s) {
+    ConvGemmArgs a{};
+    const int n_out = o.act == Q3_ACT_SWIGLU ? g.N / 2 : g.N;
+    a.X = X; a.ldx = g.K; a.x_batch_stride = (long long)L_in * g.K; a.L_in = L_in;
+    a.W = g.w; a.bias = g.bias;
+    a.Y = Y; a.ldy = n_out; a.y_batch_stride = (long long)M * n_out;
+    a.R = o.R; a.ldr = n_out; a.r_batch_stride = (long long)M * n_out;
+    a.B = B; a.M = M; a.N = g.N; a.K = g.K;
+    a.taps = g.taps; a.off0 = g.off0; a.off_step = g.off_step;
+    if (o.pro) { a.pro_a = o.pro->a; a.pro_invb = o.pro->invb; }
+    a.act = o.act;
+    if (o.epi) { a.epi_a = o.epi->a; a.epi_invb = o.epi->invb; }
+    a.scale = o.scale;
+    if (o.post) { a.post_a = o.post->a; a.post_invb = o.post->invb; }
+    if (g.taps == 1 && M == L_in) {      // no halo: batch items are just more rows
+        a.M = B * M; a.L_in = B * L_in; a.B = 1;
+    }
+    hipError_t e = q3_launch_convgemm(a, g.in_dtype, out_dtype, s);
+    if (e != hipSuccess) return fail(c, Q3C_ERR_HIP, std::string("convgemm launch: ") + hipGetErrorString(e));
+    return 0;
+}
+
+// ---- workspace layout -----------------------------------------------------------------------------------
+struct Layout {
+    size_t S = 0, Qb = 0, A = 0, Bq = 0, C = 0;           // region sizes in bytes
+    size_t oS = 0, oQ = 0, oA = 0, oB = 0, oC = 0, total = 0;
+};
+
+// Walks the stage sequence of forward() and records the largest tenant of every region.
+Layout make_layout(const q3c_ctx* c, int B, int T) {
+    const q3c_config& k = c->cfg;
+    const size_t es = esize(c->dtype);
+    const size_t fr = (size_t)B * T;
+    Layout l;
+    auto mx = [](size_t& a, size_t b) { if (b > a) a = b; };
+    if (k.frontend == Q3C_FRONTEND_SPLIT_RVQ) {
+        l.S = fr * c->G * k.codebook_dim * 4;
+        l.Qb = fr * k.rvq_out_dim * es;
+    }
+    const size_t wmax = (size_t)std::max(k.latent_dim, k.hidden_size);
+    mx(l.A, fr * wmax * es); mx(l.Bq, fr * wmax * es);
+    const size_t qd = (size_t)k.num_attention_heads * k.head_dim, kvd = (size_t)k.num_key_value_heads * k.head_dim;
+    mx(l.C, align_up(fr * (qd + 2 * kvd) * es) + align_up(fr * qd * es) + align_up(fr * k.intermediate_size * es));
+    size_t L = T;
+    for (int i = 0; i < k.num_upsampling_ratios; ++i) {
+        L *= k.upsampling_ratios[i];
+        size_t rows = (size_t)B * L;
+        mx(l.A, rows * k.latent_dim * es); mx(l.Bq, rows * k.latent_dim * es);
+        mx(l.C, align_up(rows * k.latent_dim * es) + rows * 4 * k.latent_dim * es);
+    }
+    mx(l.A, (size_t)B * L * k.decoder_dim * es); mx(l.Bq, (size_t)B * L * k.decoder_dim * es);
+    int ch = k.decoder_dim;
+    for (int i = 0; i < k.num_upsample_rates; ++i) {
+        L = (L - 1) * k.upsample_rates[i];
+        ch /= 2;
+        size_t bytes = (size_t)B * L * ch * es;
+        mx(l.A, bytes); mx(l.Bq, bytes); mx(l.C, bytes);
+    }
+    l.S = align_up(l.S); l.Qb = align_up(l.Qb); l.A = align_up(l.A); l.Bq = align_up(l.Bq); l.C = align_up(l.C);
+    l.oS = 0; l.oQ = l.oS + l.S; l.oA = l.oQ + l.Qb; l.oB = l.oA + l.A; l.oC = l.oB + l.Bq;
+    l.total = l.oC + l.C;
+    return l;
+}
+
+int tap_out(q3c_ctx* c, int stage, const void* p, size_t n, hipStream_t s) {
+    auto it = c->taps.find(stage);
+    if (it == c->taps.end() || !it->second.first) return 0;
+    if (n > it->second.second) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "tap buffer too small for stage " + std::to_string(stage));
+    hipError_t e = q3_launch_cast_to_f32(p, it->second.first, (long long)n, c->dtype, s);
+    if (e != hipSuccess) return fail(c, Q3C_ERR_HIP, std::string("tap cast: ") + hipGetErrorString(e));
+    return 0;
+}
+
+#define LAUNCH(ctx, expr)                                                                            \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess) return fail(ctx, Q3C_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+#define TRY(expr) do { int _r = (expr); if (_r) return _r; } while (0)
+
+int validate_config(q3c_ctx* c) {
+    const q3c_config& k = c->cfg;
+    auto bad = [&](const char* m) { return fail(c, Q3C_ERR_INVALID_ARGUMENT, m); };
+    if (k.struct_size != (int)sizeof(q3c_config)) return bad("q3c_config.struct_size mismatch");
+    if (k.precision != Q3C_PRECISION_F32 && k.precision != Q3C_PRECISION_BF16) return bad("unknown precision");
+    if (k.frontend != Q3C_FRONTEND_SPLIT_RVQ && k.frontend != Q3C_FRONTEND_MEAN_EMBEDDING) return bad("unknown frontend");
+    if (k.num_upsampling_ratios < 0 || k.num_upsampling_ratios > Q3C_MAX_STAGES || k.num_upsample_rates < 1 ||
+        k.num_upsample_rates > Q3C_MAX_STAGES || k.num_dilations < 1 || k.num_dilations > Q3C_MAX_STAGES)
+        return bad("stage counts out of range");
+    if (k.codebook_size < 1 || k.num_quantizers < 1 || k.num_semantic_quantizers < 1 || k.num_semantic_quantizers > k.num_quantizers)
+        return bad("codebook sizes out of range");
+    if (k.num_attention_heads % k.num_key_value_heads || (k.head_dim & 1)) return bad("attention head layout");
+    if (k.frontend == Q3C_FRONTEND_MEAN_EMBEDDING && (k.io_proj || k.latent_dim != k.hidden_size))
+        return bad("mean_embedding front end needs io_proj = 0 and latent_dim == hidden_size");
+    if (!k.io_proj && k.latent_dim != k.hidden_size) return bad("latent_dim != hidden_size needs io_proj");
+    if (k.max_positions < 1) return bad("max_positions");
+    // every contraction width must be a whole number of 16-byte pieces
+    int widths[] = {k.latent_dim, k.hidden_size, k.num_attention_heads * k.head_dim, k.num_key_value_heads * k.head_dim,
+                    k.intermediate_size, k.decoder_dim >> k.num_upsample_rates};
+    for (int w : widths) if (w % 8) return fail(c, Q3C_ERR_UNSUPPORTED, "channel counts must be multiples of 8");
+    if (k.frontend == Q3C_FRONTEND_SPLIT_RVQ && (k.codebook_dim % 4 || k.rvq_out_dim % 8))
+        return fail(c, Q3C_ERR_UNSUPPORTED, "codebook_dim must be a multiple of 4 and rvq_out_dim of 8");
+    if (k.intermediate_size % 32) return fail(c, Q3C_ERR_UNSUPPORTED, "intermediate_size must be a multiple of 32");
+    if (k.decoder_dim % (1 << k.num_upsample_rates)) return bad("decoder_dim not divisible by 2^blocks");
+    if (k.sliding_window < 1 || k.sliding_window > 256) return fail(c, Q3C_ERR_UNSUPPORTED, "sliding_window must be in [1, 256]");
+    return 0;
+}
+
+}  // namespace
+
+// =========================================================================================================
+extern "C" {
+
+const char* q3c_version(void) { return "q3c 0.1 (gfx950)"; }
+
+int q3c_create(const q3c_config* cfg, q3c_ctx** out) {
+    if (!cfg || !out) return Q3C_ERR_INVALID_ARGUMENT;
+    q3c_ctx* c = new q3c_ctx();
+    if (cfg->struct_size == (int)sizeof(q3c_config)) c->cfg = *cfg; else c->cfg.struct_size = cfg->struct_size;
+    *out = c;                       // returned even on failure so the caller can read q3c_last_error
+    int rc = validate_config(c);
+    if (rc) return rc;
+    c->dtype = cfg->precision == Q3C_PRECISION_BF16 ? Q3_BF16 : Q3_F32;
+    c->total_upsample = 1;
+    for (int i = 0; i < cfg->num_upsampling_ratios; ++i) c->total_upsample *= cfg->upsampling_ratios[i];
+    int later = 1;
+    c->trim = 0;
+    for (int i = cfg->num_upsample_rates - 1; i >= 0; --i) { later *= cfg->upsample_rates[i]; c->trim += later; }
+    c->total_upsample *= later;
+    c->G = cfg->frontend == Q3C_FRONTEND_SPLIT_RVQ ? (cfg->num_quantizers > cfg->num_semantic_quantizers ? 2 : 1) : 0;
+    return 0;
+}
+
+void q3c_destroy(q3c_ctx* c) {
+    if (!c) return;
+    for (void* p : c->allocs) (void)hipFree(p);
+    delete c;
+}
+
+const char* q3c_last_error(const q3c_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int q3c_load_weight(q3c_ctx* c, const char* name, const float* data, const int64_t* shape, int32_t ndim) {
+    if (!c) return Q3C_ERR_INVALID_ARGUMENT;
+    if (!name || !data || !shape || ndim < 1 || ndim > 4) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "q3c_load_weight: bad argument");
+    if (c->finalized) return fail(c, Q3C_ERR_STATE, "weights are frozen after q3c_finalize");
+    HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) { if (shape[i] < 0) return fail(c, Q3C_ERR_WEIGHT, "negative dimension"); t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+    t.data.assign(data, data + n);
+    c->staged[name] = std::move(t);
+    return 0;
+}
+
+int q3c_finalize(q3c_ctx* c) {
+    if (!c) return Q3C_ERR_INVALID_ARGUMENT;
+    if (c->finalized) return fail(c, Q3C_ERR_STATE, "already finalized");
+    const q3c_config& k = c->cfg;
+    const int dt = c->dtype;
+    int rc = 0;
+    void* p;
+    TRY(dev_alloc(c, 16, &p));
+    c->err_flag = (int*)p;
+    HIPCHK(c, hipMemset(c->err_flag, 0, 16));
+
+    const int H = k.hidden_size, Lt = k.latent_dim;
+    // ---- front end ----
+    if (k.frontend == Q3C_FRONTEND_MEAN_EMBEDDING) {
+        GETW(e, "code_embedding.weight", (int64_t)k.codebook_size * k.num_quantizers, H);
+        TRY(upload_f32(c, e->data, &c->emb_table));
+    } else {
+        const int ns = k.num_semantic_quantizers, D = k.codebook_dim;
+        std::vector<int> gs = {0, ns};
+        if (c->G == 2) gs.push_back(k.num_quantizers);
+        std::vector<float> proj((size_t)k.rvq_out_dim * c->G * D);
+        for (int g = 0; g < c->G; ++g) {
+            const std::string gn = g == 0 ? "semantic" : "acoustic";
+            for (int i = 0; i < gs[g + 1] - gs[g]; ++i) {
+                const std::string base = "quantizer." + gn + ".layers." + std::to_string(i) + ".";
+                GETW(es, base + "embed_sum", k.codebook_size, D);
+                GETW(cu, base + "cluster_usage", k.codebook_size);
+                std::vector<float> tab((size_t)k.codebook_size * D);
+                for (int r = 0; r < k.codebook_size; ++r) {
+                    const float den = cu->data[r] < k.rvq_eps ? k.rvq_eps : cu->data[r];      // clamp(min = eps)
+                    for (int d = 0; d < D; ++d) tab[(size_t)r * D + d] = es->data[(size_t)r * D + d] / den;   // IEEE fp32 divide
+                }
+                float* tp; TRY(upload_f32(c, tab, &tp));
+                c->tables.push_back(tp);
+            }
+            GETW(op, "quantizer." + gn + ".output_proj.weight", k.rvq_out_dim, D, 1);
+            for (int n = 0; n < k.rvq_out_dim; ++n)
+                for (int d = 0; d < D; ++d) proj[((size_t)n * c->G + g) * D + d] = op->data[(size_t)n * D + d];
+        }
+        TRY(dev_alloc(c, c->tables.size() * sizeof(float*), &p));
+        c->tables_dev = (float**)p;
+        HIPCHK(c, hipMemcpy(p, c->tables.data(), c->tables.size() * sizeof(float*), hipMemcpyHostToDevice));
+        TRY(dev_alloc(c, gs.size() * sizeof(int), &p));
+        c->group_start_dev = (int*)p;
+        HIPCHK(c, hipMemcpy(p, gs.data(), gs.size() * sizeof(int), hipMemcpyHostToDevice));
+        // both groups' 1x1 projections as ONE contraction over the concatenated sums: always fp32 operands
+        c->rvq_proj.taps = 1; c->rvq_proj.N = k.rvq_out_dim; c->rvq_proj.K = c->G * D; c->rvq_proj.in_dtype = Q3_F32;
+        TRY(upload_typed(c, proj, Q3_F32, &c->rvq_proj.w));
+        TRY(pack_conv(c, "pre_conv.conv", Lt, k.rvq_out_dim, k.pre_conv_kernel, 1, dt, &c->pre_conv));
+    }
+    if (k.io_proj) {
+        TRY(pack_linear(c, "pre_transformer.input_proj.weight", "pre_transformer.input_proj.bias", H, Lt, dt, &c->in_proj));
+        TRY(pack_linear(c, "pre_transformer.output_proj.weight", "pre_transformer.output_proj.bias", Lt, H, dt, &c->out_proj));
+    }
+    // ---- transformer ----
+    const int qd = k.num_attention_heads * k.head_dim, kvd = k.num_key_value_heads * k.head_dim, I = k.intermediate_size;
+    c->layers.resize(k.num_hidden_layers);
+    for (int l = 0; l < k.num_hidden_layers; ++l) {
+        Layer& y = c->layers[l];
+        const std::string pre = "pre_transformer.layers." + std::to_string(l) + ".";
+        TRY(pack_vec(c, pre + "input_layernorm.weight", H, &y.ln1));
+        TRY(pack_vec(c, pre + "post_attention_layernorm.weight", H, &y.ln2));
+        TRY(pack_vec(c, pre + "self_attn_layer_scale.scale", H, &y.ls_attn));
+        TRY(pack_vec(c, pre + "mlp_layer_scale.scale", H, &y.ls_mlp));
+        GETW(wq, pre + "self_attn.q_proj.weight", qd, H);
+        GETW(wk, pre + "self_attn.k_proj.weight", kvd, H);
+        GETW(wv, pre + "self_attn.v_proj.weight", kvd, H);
+        std::vector<float> cat;
+        cat.reserve((size_t)(qd + 2 * kvd) * H);
+        cat.insert(cat.end(), wq->data.begin(), wq->data.end());
+        cat.insert(cat.end(), wk->data.begin(), wk->data.end());
+        cat.insert(cat.end(), wv->data.begin(), wv->data.end());
+        y.qkv.taps = 1; y.qkv.N = qd + 2 * kvd; y.qkv.K = H; y.qkv.in_dtype = dt;
+        TRY(upload_typed(c, cat, dt, &y.qkv.w));
+        TRY(pack_linear(c, pre + "self_attn.o_proj.weight", "", H, qd, dt, &y.o));
+        GETW(wg, pre + "mlp.gate_proj.weight", I, H);
+        GETW(wu, pre + "mlp.up_proj.weight", I, H);
+        std::vector<float> gu((size_t)2 * I * H);     // 32-row blocks alternate gate / up so one lane owns both halves
+        for (int blk = 0; blk < I / 32; ++blk)
+            for (int r = 0; r < 32; ++r) {
+                std::memcpy(&gu[((size_t)(2 * blk) * 32 + r) * H], &wg->data[((size_t)blk * 32 + r) * H], (size_t)H * 4);
+                std::memcpy(&gu[((size_t)(2 * blk + 1) * 32 + r) * H], &wu->data[((size_t)blk * 32 + r) * H], (size_t)H * 4);
+            }
+        y.gu.taps = 1; y.gu.N = 2 * I; y.gu.K = H; y.gu.in_dtype = dt;
+        TRY(upload_typed(c, gu, dt, &y.gu.w));
+        TRY(pack_linear(c, pre + "mlp.down_proj.weight", "", H, I, dt, &y.down));
+    }
+    TRY(pack_vec(c, "pre_transformer.norm.weight", H, &c->final_norm));
+    {   // rotary tables: freq = float(pos) * inv_freq in fp32, then cos / sin of that fp32 angle
+        const int half = k.head_dim / 2;
+        GETW(inv, "rope.inv_freq", half);
+        std::vector<float> ct((size_t)k.max_positions * half), st(ct.size());
+        for (int pos = 0; pos < k.max_positions; ++pos)
+            for (int e = 0; e < half; ++e) {
+                const float ang = (float)pos * inv->data[e];
+                ct[(size_t)pos * half + e] = (float)std::cos((double)ang);
+                st[(size_t)pos * half + e] = (float)std::sin((double)ang);
+            }
+        TRY(upload_f32(c, ct, &c->cos_t));
+        TRY(upload_f32(c, st, &c->sin_t));
+    }
+    // ---- upsample stages ----
+    c->ups.resize(k.num_upsampling_ratios);
+    for (int i = 0; i < k.num_upsampling_ratios; ++i) {
+        UpStage& u = c->ups[i];
+        u.f = k.upsampling_ratios[i];
+        const std::string pre = "upsample." + std::to_string(i) + ".";
+        TRY(pack_tconv(c, pre + "0.conv", Lt, Lt, u.f, u.f, dt, &u.tconv));
+        GETW(dw, pre + "1.dwconv.conv.weight", Lt, 1, 7);
+        std::vector<float> dwt((size_t)7 * Lt);
+        for (int ch = 0; ch < Lt; ++ch)
+            for (int j = 0; j < 7; ++j) dwt[(size_t)j * Lt + ch] = dw->data[(size_t)ch * 7 + j];
+        TRY(upload_f32(c, dwt, &u.dw_w));
+        TRY(pack_vec(c, pre + "1.dwconv.conv.bias", Lt, &u.dw_b));
+        TRY(pack_vec(c, pre + "1.norm.weight", Lt, &u.ln_w));
+        TRY(pack_vec(c, pre + "1.norm.bias", Lt, &u.ln_b));
+        TRY(pack_linear(c, pre + "1.pwconv1.weight", pre + "1.pwconv1.bias", 4 * Lt, Lt, dt, &u.pw1));
+        TRY(pack_linear(c, pre + "1.pwconv2.weight", pre + "1.pwconv2.bias", Lt, 4 * Lt, dt, &u.pw2));
+        TRY(pack_vec(c, pre + "1.gamma", Lt, &u.gamma));
+    }
+    // ---- conv decoder ----
+    TRY(pack_conv(c, "decoder.0.conv", k.decoder_dim, Lt, 7, 1, dt, &c->conv_in));
+    c->blocks.resize(k.num_upsample_rates);
+    int ch = k.decoder_dim;
+    for (int i = 0; i < k.num_upsample_rates; ++i) {
+        Block& b = c->blocks[i];
+        const int cin = ch, cout = ch / 2, r = k.upsample_rates[i];
+        b.rate = r;
+        const std::string pre = "decoder." + std::to_string(i + 1) + ".block.";
+        TRY(pack_snake(c, pre + "0.", cin, &b.head));
+        TRY(pack_tconv(c, pre + "1.conv", cin, cout, 2 * r, r, dt, &b.tconv));
+        b.units.resize(k.num_dilations);
+        for (int j = 0; j < k.num_dilations; ++j) {
+            Unit& u = b.units[j];
+            const std::string q = pre + std::to_string(j + 2) + ".";
+            TRY(pack_snake(c, q + "act1.", cout, &u.a1));
+            TRY(pack_conv(c, q + "conv1.conv", cout, cout, 7, k.dilations[j], dt, &u.c1));
+            TRY(pack_snake(c, q + "act2.", cout, &u.a2));
+            TRY(pack_conv(c, q + "conv2.conv", cout, cout, 1, 1, dt, &u.c2));
+        }
+        ch = cout;
+    }
+    const int nb = k.num_upsample_rates;
+    TRY(pack_snake(c, "decoder." + std::to_string(nb + 1) + ".", ch, &c->final_snake));
+    {
+        GETW(w, "decoder." + std::to_string(nb + 2) + ".conv.weight", 1, ch, 7);
+        GETW(b, "decoder." + std::to_string(nb + 2) + ".conv.bias", 1);
+        std::vector<float> wt((size_t)7 * ch);
+        for (int cc = 0; cc < ch; ++cc)
+            for (int j = 0; j < 7; ++j) wt[(size_t)j * ch + cc] = w->data[(size_t)cc * 7 + j];
+        TRY(upload_f32(c, wt, &c->out_w));
+        c->out_b = b->data[0];
+        c->out_k = 7;
+    }
+    c->staged.clear();
+    c->finalized = true;
+    return 0;
+}
+
+int q3c_output_length(const q3c_ctx* c, int32_t frames, int64_t* samples) {
+    if (!c || !samples || frames < 1) return Q3C_ERR_INVALID_ARGUMENT;
+    *samples = (int64_t)frames * c->total_upsample - c->trim;
+    return 0;
+}
+
+int q3c_workspace_bytes(q3c_ctx* c, int32_t B, int32_t T, size_t* bytes) {
+    if (!c || !bytes) return Q3C_ERR_INVALID_ARGUMENT;
+    if (B < 1 || T < 1) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "batch and frames must be >= 1");
+    *bytes = make_layout(c, B, T).total;
+    return 0;
+}
+
+int q3c_set_tap(q3c_ctx* c, int32_t stage, float* buf, size_t cap) {
+    if (!c) return Q3C_ERR_INVALID_ARGUMENT;
+    if (!buf) c->taps.erase(stage); else c->taps[stage] = {buf, cap};
+    return 0;
+}
+
+int q3c_check_errors(q3c_ctx* c, void* stream) {
+    if (!c || !c->finalized) return Q3C_ERR_STATE;
+    int flag = 0;
+    HIPCHK(c, hipMemcpyAsync(&flag, c->err_flag, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(c, hipStreamSynchronize((hipStream_t)stream));
+    if (flag) {
+        HIPCHK(c, hipMemsetAsync(c->err_flag, 0, sizeof(int), (hipStream_t)stream));
+        return fail(c, Q3C_ERR_CODES, "a code index was outside [0, codebook_size)");
+    }
+    return 0;
+}
+
+int q3c_rvq_dequant_f32(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, float* sums, void* stream) {
+    if (!c) return Q3C_ERR_INVALID_ARGUMENT;
+    if (!c->finalized) return fail(c, Q3C_ERR_STATE, "q3c_finalize has not run");
+    if (c->cfg.frontend != Q3C_FRONTEND_SPLIT_RVQ) return fail(c, Q3C_ERR_STATE, "context has no RVQ front end");
+    if (!codes || !sums || B < 1 || T < 1) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "q3c_rvq_dequant_f32: bad argument");
+    LAUNCH(c, q3_launch_rvq_gather_sum((const long long*)codes, B, c->cfg.num_quantizers, T, c->cfg.codebook_size, c->cfg.codebook_dim,
+                                       c->tables_dev, c->group_start_dev, c->G, sums, c->err_flag, (hipStream_t)stream));
+    return 0;
+}
+
+int q3c_forward(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, float* wav, void* ws, size_t ws_bytes, void* stream) {
+    if (!c) return Q3C_ERR_INVALID_ARGUMENT;
+    if (!c->finalized) return fail(c, Q3C_ERR_STATE, "q3c_finalize has not run");
+    if (!codes || !wav || !ws || B < 1 || T < 1) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "q3c_forward: bad argument");
+    const q3c_config& k = c->cfg;
+    if (T > k.max_positions) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "frames exceed max_positions");
+    if ((uintptr_t)ws & 255) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "workspace must be 256-byte aligned");
+    const Layout lay = make_layout(c, B, T);
+    if (ws_bytes < lay.total) return fail(c, Q3C_ERR_WORKSPACE, "workspace too small: need " + std::to_string(lay.total));
+    hipStream_t s = (hipStream_t)stream;
+    const int dt = c->dtype;
+    const size_t es = esize(dt);
+    char* base = (char*)ws;
+    float* S = (float*)(base + lay.oS);
+    void* Qb = base + lay.oQ;
+    void* bufA = base + lay.oA;
+    void* bufB = base + lay.oB;
+    char* bufC = base + lay.oC;
+    const size_t fr = (size_t)B * T;
+    const int H = k.hidden_size, Lt = k.latent_dim;
+
+    // ---- front end -> x0 [B,T,Lt] in bufA ----
+    if (k.frontend == Q3C_FRONTEND_MEAN_EMBEDDING) {
+        LAUNCH(c, q3_launch_mean_embedding((const long long*)codes, B, k.num_quantizers, T, k.codebook_size, H, c->emb_table, bufA, dt,
+                                           c->err_flag, s));
+    } else {
+        LAUNCH(c, q3_launch_rvq_gather_sum((const long long*)codes, B, k.num_quantizers, T, k.codebook_size, k.codebook_dim,
+                                           c->tables_dev, c->group_start_dev, c->G, S, c->err_flag, s));
+        TRY(gemm(c, c->rvq_proj, S, B, T, Qb, T, dt, GemmOpts{}, s));
+        TRY(tap_out(c, Q3C_STAGE_RVQ_OUT, Qb, fr * k.rvq_out_dim, s));
+        TRY(gemm(c, c->pre_conv, Qb, B, T, bufA, T, dt, GemmOpts{}, s));
+    }
+    TRY(tap_out(c, Q3C_STAGE_TRANSFORMER_IN, bufA, fr * Lt, s));
+
+    // ---- transformer ----
+    void* x = bufA; void* nrm = bufB;
+    if (k.io_proj) { TRY(gemm(c, c->in_proj, bufA, B, T, bufB, T, dt, GemmOpts{}, s)); x = bufB; nrm = bufA; }
+    const int qd = k.num_attention_heads * k.head_dim, kvd = k.num_key_value_heads * k.head_dim;
+    void* qkv = bufC;
+    void* att = bufC + align_up(fr * (qd + 2 * kvd) * es);
+    void* mlp = (char*)att + align_up(fr * qd * es);
+    for (int l = 0; l < k.num_hidden_layers; ++l) {
+        const Layer& y = c->layers[l];
+        LAUNCH(c, q3_launch_rmsnorm(x, y.ln1, nrm, (long long)fr, H, k.rms_norm_eps, dt, s));
+        TRY(gemm(c, y.qkv, nrm, B, T, qkv, T, dt, GemmOpts{}, s));
+        LAUNCH(c, q3_launch_swa_attention(qkv, att, c->cos_t, c->sin_t, B, T, k.num_attention_heads, k.num_key_value_heads, k.head_dim,
+                                          k.sliding_window, dt, s));
+        GemmOpts o1; o1.scale = y.ls_attn; o1.R = x;
+        TRY(gemm(c, y.o, att, B, T, x, T, dt, o1, s));
+        LAUNCH(c, q3_launch_rmsnorm(x, y.ln2, nrm, (long long)fr, H, k.rms_norm_eps, dt, s));
+        GemmOpts o2; o2.act = Q3_ACT_SWIGLU;
+        TRY(gemm(c, y.gu, nrm, B, T, mlp, T, dt, o2, s));
+        GemmOpts o3; o3.scale = y.ls_mlp; o3.R = x;
+        TRY(gemm(c, y.down, mlp, B, T, x, T, dt, o3, s));
+    }
+    LAUNCH(c, q3_launch_rmsnorm(x, c->final_norm, nrm, (long long)fr, H, k.rms_norm_eps, dt, s));
+    void* cur; void* other;
+    if (k.io_proj) { TRY(gemm(c, c->out_proj, nrm, B, T, x, T, dt, GemmOpts{}, s)); cur = x; other = nrm; }
+    else { cur = nrm; other = x; }
+    TRY(tap_out(c, Q3C_STAGE_TRANSFORMER_OUT, cur, fr * Lt, s));
+
+    // ---- upsample stages: transposed conv (k = s = f) then ConvNeXt ----
+    int L = T;
+    for (int i = 0; i < k.num_upsampling_ratios; ++i) {
+        const UpStage& u = c->ups[i];
+        TRY(gemm(c, u.tconv, cur, B, L, other, L, dt, GemmOpts{}, s));       // [B, L, f*Lt] == [B, L*f, Lt]
+        L *= u.f;
+        const size_t rows = (size_t)B * L;
+        void* d = bufC;
+        void* pw = bufC + align_up(rows * Lt * es);
+        LAUNCH(c, q3_launch_dwconv_ln(other, u.dw_w, u.dw_b, u.ln_w, u.ln_b, d, B, L, Lt, 7, k.convnext_eps, dt, s));
+        GemmOpts g1; g1.act = Q3_ACT_GELU;
+        TRY(gemm(c, u.pw1, d, B, L, pw, L, dt, g1, s));
+        GemmOpts g2; g2.scale = u.gamma; g2.R = other;
+        TRY(gemm(c, u.pw2, pw, B, L, other, L, dt, g2, s));
+        std::swap(cur, other);
+        TRY(tap_out(c, Q3C_STAGE_UPSAMPLE0 + i, cur, rows * Lt, s));
+    }
+
+    // ---- conv decoder ----
+    {
+        GemmOpts g; g.post = &c->blocks[0].head;
+        TRY(gemm(c, c->conv_in, cur, B, L, other, L, dt, g, s));
+        std::swap(cur, other);
+        TRY(tap_out(c, Q3C_STAGE_CONV_IN, cur, (size_t)B * L * k.decoder_dim, s));
+    }
+    int ch = k.decoder_dim;
+    for (size_t i = 0; i < c->blocks.size(); ++i) {
+        const Block& b = c->blocks[i];
+        if (L < 2) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "sequence too short for the transposed convolutions");
+        const int Lq = L - 1;
+        ch /= 2;
+        TRY(gemm(c, b.tconv, cur, B, L, other, Lq, dt, GemmOpts{}, s));       // [B, L-1, r*ch] == [B, (L-1)*r, ch]
+        L = Lq * b.rate;
+        void* t = other; void* hh = bufC;
+        for (size_t j = 0; j < b.units.size(); ++j) {
+            const Unit& u = b.units[j];
+            GemmOpts g1; g1.pro = &u.a1; g1.act = Q3_ACT_SNAKE; g1.epi = &u.a2;
+            TRY(gemm(c, u.c1, t, B, L, hh, L, dt, g1, s));
+            GemmOpts g2; g2.R = t;
+            if (j + 1 == b.units.size()) g2.post = (i + 1 < c->blocks.size()) ? &c->blocks[i + 1].head : &c->final_snake;
+            TRY(gemm(c, u.c2, hh, B, L, t, L, dt, g2, s));
+        }
+        std::swap(cur, other);
+        TRY(tap_out(c, Q3C_STAGE_BLOCK0 + (int)i, cur, (size_t)B * L * ch, s));
+    }
+    LAUNCH(c, q3_launch_conv_out(cur, c->out_w, c->out_b, wav, B, L, ch, c->out_k, dt, s));
+    return 0;
+}
+
+// ---- single operators ---------------------------------------------------------------------------------------
+static int op_run(GemmW& g, q3c_ctx* c, const float* x, int B, int L_in, int cin, float* y, int M, int n_out, int precision,
+                  hipStream_t s) {
+    const int dt = precision == Q3C_PRECISION_BF16 ? Q3_BF16 : Q3_F32;
+    void *xi = nullptr, *yo = nullptr;
+    int rc = 0;
+    if (dt == Q3_BF16) {
+        TRY(dev_alloc(c, (size_t)B * L_in * cin * 2, &xi));
+        TRY(dev_alloc(c, (size_t)B * M * n_out * 2, &yo));
+        LAUNCH(c, q3_launch_cast_from_f32(x, xi, (long long)B * L_in * cin, dt, s));
+        rc = gemm(c, g, xi, B, L_in, yo, M, dt, GemmOpts{}, s);
+        if (rc) return rc;
+        LAUNCH(c, q3_launch_cast_to_f32(yo, y, (long long)B * M * n_out, dt, s));
+    } else {
+        rc = gemm(c, g, x, B, L_in, y, M, dt, GemmOpts{}, s);
+        if (rc) return rc;
+    }
+    HIPCHK(c, hipStreamSynchronize(s));
+    return 0;
+}
+
+int q3c_causal_conv1d(const float* x, int32_t B, int32_t L, int32_t cin, int32_t cout, int32_t k, int32_t dil, const float* w,
+                      const float* bias, float* y, int32_t precision, void* stream) {
+    if (!x || !w || !y || B < 1 || L < 1 || cin % 8 || cout < 1 || k < 1 || dil < 1) return Q3C_ERR_INVALID_ARGUMENT;
+    q3c_ctx tmp;
+    const int dt = precision == Q3C_PRECISION_BF16 ? Q3_BF16 : Q3_F32;
+    tmp.staged["w.weight"] = HostTensor{{cout, cin, k}, std::vector<float>(w, w + (size_t)cout * cin * k)};
+    if (bias) tmp.staged["w.bias"] = HostTensor{{cout}, std::vector<float>(bias, bias + cout)};
+    GemmW g;
+    int rc = pack_conv(&tmp, "w", cout, cin, k, dil, dt, &g, bias != nullptr);
+    if (!rc) rc = op_run(g, &tmp, x, B, L, cin, y, L, cout, precision, (hipStream_t)stream);
+    if (rc) fprintf(stderr, "q3c_causal_conv1d: %s\n", tmp.err.c_str());
+    for (void* p : tmp.allocs) (void)hipFree(p);
+    return rc;
+}
+
+int q3c_causal_tconv1d(const float* x, int32_t B, int32_t L, int32_t cin, int32_t cout, int32_t k, int32_t stride, const float* w,
+                       const float* bias, float* y, int32_t precision, void* stream) {
+    if (!x || !w || !y || B < 1 || L < 1 || cin % 8 || cout < 1 || stride < 1) return Q3C_ERR_INVALID_ARGUMENT;
+    q3c_ctx tmp;
+    const int dt = precision == Q3C_PRECISION_BF16 ? Q3_BF16 : Q3_F32;
+    GemmW g;
+    int rc = pack_tconv_host(&tmp, w, bias, cin, cout, k, stride, dt, &g);
+    const int M = (k == stride) ? L : L - 1;
+    if (!rc && M >= 1) rc = op_run(g, &tmp, x, B, L, cin, y, M, stride * cout, precision, (hipStream_t)stream);
+    if (rc) fprintf(stderr, "q3c_causal_tconv1d: %s\n", tmp.err.c_str());
+    for (void* p : tmp.allocs) (void)hipFree(p);
+    return rc;
+}
+
+int q3c_snake_beta(const float* x, int64_t rows, int32_t C, const float* alpha, const float* beta, float eps, float* y, void* stream) {
+    if (!x || !y || !alpha || !beta || rows < 0 || C < 1) return Q3C_ERR_INVALID_ARGUMENT;
+    q3c_ctx tmp;
+    Snake sn;
+    int rc = pack_snake_host(&tmp, alpha, beta, C, eps, &sn);
+    if (!rc) {
+        hipError_t e = q3_launch_snake(x, y, sn.a, sn.invb, rows, C, Q3_F32, (hipStream_t)stream);
+        if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+        if (e != hipSuccess) rc = Q3C_ERR_HIP;
+    }
+    for (void* p : tmp.allocs) (void)hipFree(p);
+    return rc;
+}
+
+}  // extern "C"

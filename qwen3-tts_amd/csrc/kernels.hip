@@ -1,0 +1,426 @@
+// The decode's bandwidth-bound kernels: RVQ gather-and-sum, mean embedding, RMSNorm, depthwise conv + LayerNorm,
+// sliding-window attention with fused RoPE, the final 1-channel conv + clamp, and small utilities.
+// All tensors are channels-last [batch, time, channel].
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// RVQ gather-and-sum, fp32, bit-exact.  One thread owns 4 consecutive dims of one frame and walks the
+// codebooks of each group in order:  acc = +0.0; acc = acc + row_q  (one IEEE add per codebook, no FMA,
+// no reassociation) - the order of `quantized_out = quantized_out + quantized` in the Mimi RVQ decode.
+// Tables (16 x 2048 x 256 x 4 B = 32 MiB at full size) exceed LDS; they stay L2 / Infinity-Cache resident
+// and each frame's row is read as whole 16-byte pieces by consecutive lanes.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) rvq_gather_sum_kernel(const long long* __restrict__ codes, int B, int Q, int T, int bins,
+                                                             int D, const float* const* __restrict__ tables,
+                                                             const int* __restrict__ group_start /*[G+1]*/, int G,
+                                                             float* __restrict__ out, int* err_flag) {
+    const int vpr = D >> 2;
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long frame = idx / vpr;
+    int vec = (int)(idx - frame * vpr);
+    if (frame >= (long long)B * T) return;
+    int b = (int)(frame / T), t = (int)(frame - (long long)b * T);
+    for (int g = 0; g < G; ++g) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = group_start[g]; q < group_start[g + 1]; ++q) {
+            long long code = codes[((long long)b * Q + q) * T + t];
+            if (code < 0 || code >= bins) { atomicOr(err_flag, 1); code = 0; }
+            const float4 row = *(const float4*)(tables[q] + (size_t)code * D + vec * 4);
+            acc.x = __fadd_rn(acc.x, row.x); acc.y = __fadd_rn(acc.y, row.y);
+            acc.z = __fadd_rn(acc.z, row.z); acc.w = __fadd_rn(acc.w, row.w);
+        }
+        *(float4*)(out + ((size_t)frame * G + g) * D + vec * 4) = acc;
+    }
+}
+
+// Embedding(Q*bins, H)(codes + q*bins).mean(1): ordered sum then divide by Q.
+template <typename T>
+__global__ void __launch_bounds__(256) mean_embedding_kernel(const long long* __restrict__ codes, int B, int Q, int Tn, int bins,
+                                                             int H, const float* __restrict__ table, T* __restrict__ out,
+                                                             int* err_flag) {
+    const int vpr = H >> 2;
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long frame = idx / vpr;
+    int vec = (int)(idx - frame * vpr);
+    if (frame >= (long long)B * Tn) return;
+    int b = (int)(frame / Tn), t = (int)(frame - (long long)b * Tn);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < Q; ++q) {
+        long long code = codes[((long long)b * Q + q) * Tn + t];
+        if (code < 0 || code >= bins) { atomicOr(err_flag, 1); code = 0; }
+        const float4 row = *(const float4*)(table + ((size_t)q * bins + code) * H + vec * 4);
+        acc.x += row.x; acc.y += row.y; acc.z += row.z; acc.w += row.w;
+    }
+    const float fq = (float)Q;
+    T* o = out + (size_t)frame * H + vec * 4;
+    o[0] = q3_from_f32<T>(acc.x / fq); o[1] = q3_from_f32<T>(acc.y / fq);
+    o[2] = q3_from_f32<T>(acc.z / fq); o[3] = q3_from_f32<T>(acc.w / fq);
+}
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// RMSNorm: y = w * (x * rsqrt(mean(x^2) + eps)); one wave per row, fp32 math.
+template <typename T>
+__global__ void __launch_bounds__(256) rmsnorm_kernel(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y,
+                                                      long long rows, int H, float eps) {
+    long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const T* xr = x + row * H;
+    float ss = 0.f;
+    for (int i = lane; i < H; i += 64) { float v = q3_to_f32(xr[i]); ss += v * v; }
+    ss = wave_sum(ss);
+    const float r = rsqrtf(ss / (float)H + eps);
+    T* yr = y + row * H;
+    for (int i = lane; i < H; i += 64) yr[i] = q3_from_f32<T>(w[i] * (q3_to_f32(xr[i]) * r));
+}
+
+// Depthwise causal conv (kernel k, weights [k][C]) followed by LayerNorm over C.  One block per (b, t) row.
+template <typename T, int CPT>
+__global__ void __launch_bounds__(256) dwconv_ln_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, const float* __restrict__ lnw,
+                                                        const float* __restrict__ lnb, T* __restrict__ y, int L, int C, int k,
+                                                        float eps) {
+    __shared__ float red[8];
+    const long long row = blockIdx.x;            // b * L + t
+    const int t = (int)(row % L);
+    const int tid = threadIdx.x;
+    float v[CPT];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        int c = tid + i * 256;
+        float a = 0.f;
+        if (c < C) {
+            a = bias[c];
+            for (int j = 0; j < k; ++j) {
+                int tt = t - (k - 1) + j;
+                if (tt >= 0) a += w[j * C + c] * q3_to_f32(x[(row - t + tt) * C + c]);
+            }
+            s += a;
+        }
+        v[i] = a;
+    }
+    s = wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        int c = tid + i * 256;
+        if (c < C) { float d = v[i] - mean; q += d * d; }
+    }
+    q = wave_sum(q);
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = q;
+    __syncthreads();
+    const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        int c = tid + i * 256;
+        if (c < C) y[row * C + c] = q3_from_f32<T>((v[i] - mean) * rstd * lnw[c] + lnb[c]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sliding-window causal attention with rotary embedding fused into the Q/K staging.
+// qkv rows are [q (nh*d) | k (nkv*d) | v (nkv*d)].  One block = (32 queries, one head, one batch item);
+// keys [max(0, q0 - W + 1), q0 + 31] and their values sit in LDS as fp32; one wave walks 8 queries:
+// lane = key for the scores (softmax by wave reductions, fp32), lane = dim for P.V.
+// ------------------------------------------------------------------------------------------------
+constexpr int ATT_QT = 32;
+constexpr int ATT_MAXC = 4;   // window <= 64 * ATT_MAXC
+
+template <typename T>
+__global__ void __launch_bounds__(256) swa_attention_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+                                                            const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                                            int Tn, int nh, int nkv, int d, int window, float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_att[];
+    const int q0 = blockIdx.x * ATT_QT;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int hk = h / (nh / nkv);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q_hi = min(q0 + ATT_QT, Tn) - 1;
+    const int k_lo = max(0, q0 - window + 1);
+    const int nk = q_hi - k_lo + 1;
+    const int nkmax = ATT_QT + window - 1;
+    const int ds = d + 1;                          // padded row stride: lane = key reads hit distinct banks
+    const int half = d >> 1;
+    float* Ks = (float*)smem_att;
+    float* Vs = Ks + (size_t)nkmax * ds;
+    float* Qs = Vs + (size_t)nkmax * ds;
+    float* Ps = Qs + (size_t)ATT_QT * d + (size_t)wave * 64 * ATT_MAXC;
+    const int rs = (nh + 2 * nkv) * d;             // qkv row stride
+    const T* base = qkv + (size_t)b * Tn * rs;
+
+    for (int i = tid; i < nk * half; i += 256) {
+        int r = i / half, e = i - r * half;
+        int pos = k_lo + r;
+        const T* kr = base + (size_t)pos * rs + (nh + hk) * d;
+        const T* vr = kr + nkv * d;
+        float c = cos_t[(size_t)pos * half + e], s = sin_t[(size_t)pos * half + e];
+        float x1 = q3_to_f32(kr[e]), x2 = q3_to_f32(kr[e + half]);
+        Ks[r * ds + e] = x1 * c - x2 * s;
+        Ks[r * ds + e + half] = x2 * c + x1 * s;
+        Vs[r * ds + e] = q3_to_f32(vr[e]);
+        Vs[r * ds + e + half] = q3_to_f32(vr[e + half]);
+    }
+    const int nq = q_hi - q0 + 1;
+    for (int i = tid; i < nq * half; i += 256) {
+        int r = i / half, e = i - r * half;
+        int pos = q0 + r;
+        const T* qr = base + (size_t)pos * rs + h * d;
+        float c = cos_t[(size_t)pos * half + e], s = sin_t[(size_t)pos * half + e];
+        float x1 = q3_to_f32(qr[e]), x2 = q3_to_f32(qr[e + half]);
+        Qs[r * d + e] = x1 * c - x2 * s;
+        Qs[r * d + e + half] = x2 * c + x1 * s;
+    }
+    __syncthreads();
+
+    const int nchunk = (window + 63) >> 6;
+    for (int qi = wave; qi < nq; qi += 4) {
+        const int i = q0 + qi;
+        const int jlo = max(0, i - window + 1);
+        const float* qv = Qs + qi * d;
+        float sc[ATT_MAXC];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < ATT_MAXC; ++c) {
+            sc[c] = -INFINITY;
+            if (c < nchunk) {
+                int j = jlo + lane + 64 * c;
+                if (j <= i) {
+                    const float* kr = Ks + (size_t)(j - k_lo) * ds;
+                    float a = 0.f;
+                    for (int e = 0; e < d; ++e) a += qv[e] * kr[e];
+                    sc[c] = a * scale;
+                }
+                mx = fmaxf(mx, sc[c]);
+            }
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < ATT_MAXC; ++c) {
+            float pv = 0.f;
+            if (c < nchunk && sc[c] != -INFINITY) pv = expf(sc[c] - mx);
+            sc[c] = pv;
+            sum += pv;
+        }
+        sum = wave_sum(sum);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int c = 0; c < ATT_MAXC; ++c)
+            if (c < nchunk) Ps[lane + 64 * c] = sc[c] * inv;
+        // Ps is private to this wave; LDS ops of one wave complete in order, so no workgroup barrier is needed.
+        __builtin_amdgcn_wave_barrier();
+        const int cnt = i - jlo + 1;
+        for (int e = lane; e < d; e += 64) {
+            float a = 0.f;
+            const float* vr = Vs + (size_t)(jlo - k_lo) * ds + e;
+            for (int j = 0; j < cnt; ++j) a += Ps[j] * vr[(size_t)j * ds];
+            out[((size_t)b * Tn + i) * (nh * d) + h * d + e] = q3_from_f32<T>(a);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Final conv C -> 1 (kernel k, causal) + clamp(-1, 1).  x already carries the last SnakeBeta.
+// One thread per output sample; its k input rows overlap its neighbours' rows, so the re-reads are L1 hits.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) conv_out_kernel(const T* __restrict__ x, const float* __restrict__ w, float bias,
+                                                       float* __restrict__ wav, int L, int C, int k) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_co[];
+    float* ws = (float*)smem_co;
+    for (int i = threadIdx.x; i < k * C; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= L) return;
+    constexpr int EPC = ElemTraits<T>::EPC;
+    const T* xb = x + (size_t)b * L * C;
+    float acc = bias;
+    for (int j = 0; j < k; ++j) {
+        int tt = t - (k - 1) + j;
+        if (tt < 0) continue;
+        const T* xr = xb + (size_t)tt * C;
+        const float* wr = ws + j * C;
+        for (int c = 0; c < C; c += EPC) {
+            uint4 raw = *(const uint4*)(xr + c);
+            if constexpr (EPC == 8) {
+                bf16x8 hv = __builtin_bit_cast(bf16x8, raw);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc += wr[c + e] * (float)hv[e];
+            } else {
+                acc += wr[c] * __builtin_bit_cast(float, raw.x) + wr[c + 1] * __builtin_bit_cast(float, raw.y) +
+                       wr[c + 2] * __builtin_bit_cast(float, raw.z) + wr[c + 3] * __builtin_bit_cast(float, raw.w);
+            }
+        }
+    }
+    wav[(size_t)b * L + t] = fminf(1.0f, fmaxf(-1.0f, acc));
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) cast_to_f32_kernel(const T* __restrict__ x, float* __restrict__ y, long long n) {
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long stride = (long long)gridDim.x * 256;
+    for (; i < n; i += stride) y[i] = q3_to_f32(x[i]);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) cast_from_f32_kernel(const float* __restrict__ x, T* __restrict__ y, long long n) {
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long stride = (long long)gridDim.x * 256;
+    for (; i < n; i += stride) y[i] = q3_from_f32<T>(x[i]);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) snake_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ a,
+                                                    const float* __restrict__ invb, long long n, int C) {
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long stride = (long long)gridDim.x * 256;
+    for (; i < n; i += stride) {
+        int c = (int)(i % C);
+        y[i] = q3_from_f32<T>(q3_snake<T>(q3_to_f32(x[i]), a[c], invb[c]));
+    }
+}
+
+inline unsigned grid_for(long long n, int per_block) {
+    long long g = (n + per_block - 1) / per_block;
+    return (unsigned)g;
+}
+
+}  // namespace
+
+hipError_t q3_launch_rvq_gather_sum(const long long* codes, int B, int Q, int T, int bins, int D,
+                                    const float* const* tables_dev, const int* group_start_dev, int G,
+                                    float* out, int* err_flag, hipStream_t s) {
+    if (D % 4) return hipErrorInvalidValue;
+    long long n = (long long)B * T * (D / 4);
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(rvq_gather_sum_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, codes, B, Q, T, bins, D, tables_dev,
+                       group_start_dev, G, out, err_flag);
+    return hipGetLastError();
+}
+
+hipError_t q3_launch_mean_embedding(const long long* codes, int B, int Q, int T, int bins, int H, const float* table, void* out,
+                                    int out_dtype, int* err_flag, hipStream_t s) {
+    if (H % 4) return hipErrorInvalidValue;
+    long long n = (long long)B * T * (H / 4);
+    if (n == 0) return hipSuccess;
+    if (out_dtype == Q3_BF16)
+        hipLaunchKernelGGL(mean_embedding_kernel<bf16>, dim3(grid_for(n, 256)), dim3(256), 0, s, codes, B, Q, T, bins, H, table,
+                           (bf16*)out, err_flag);
+    else
+        hipLaunchKernelGGL(mean_embedding_kernel<float>, dim3(grid_for(n, 256)), dim3(256), 0, s, codes, B, Q, T, bins, H, table,
+                           (float*)out, err_flag);
+    return hipGetLastError();
+}
+
+hipError_t q3_launch_rmsnorm(const void* x, const float* w, void* y, long long rows, int H, float eps, int dtype, hipStream_t s) {
+    if (rows == 0) return hipSuccess;
+    dim3 grid(grid_for(rows, 4));
+    if (dtype == Q3_BF16)
+        hipLaunchKernelGGL(rmsnorm_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)x, w, (bf16*)y, rows, H, eps);
+    else
+        hipLaunchKernelGGL(rmsnorm_kernel<float>, grid, dim3(256), 0, s, (const float*)x, w, (float*)y, rows, H, eps);
+    return hipGetLastError();
+}
+
+hipError_t q3_launch_dwconv_ln(const void* x, const float* w, const float* b, const float* lnw, const float* lnb, void* y, int B,
+                               int L, int C, int k, float eps, int dtype, hipStream_t s) {
+    long long rows = (long long)B * L;
+    if (rows == 0) return hipSuccess;
+    if (C > 256 * 8) return hipErrorInvalidValue;
+    dim3 grid((unsigned)rows);
+#define Q3_DW(TT, CPT) hipLaunchKernelGGL((dwconv_ln_kernel<TT, CPT>), grid, dim3(256), 0, s, (const TT*)x, w, b, lnw, lnb, (TT*)y, L, C, k, eps)
+    const int cpt = (C + 255) / 256;
+    if (dtype == Q3_BF16) {
+        if (cpt <= 1) Q3_DW(bf16, 1); else if (cpt <= 4) Q3_DW(bf16, 4); else Q3_DW(bf16, 8);
+    } else {
+        if (cpt <= 1) Q3_DW(float, 1); else if (cpt <= 4) Q3_DW(float, 4); else Q3_DW(float, 8);
+    }
+#undef Q3_DW
+    return hipGetLastError();
+}
+
+hipError_t q3_launch_swa_attention(const void* qkv, void* out, const float* cos_t, const float* sin_t, int B, int T, int nh,
+                                   int nkv, int d, int window, int dtype, hipStream_t s) {
+    if (B == 0 || T == 0) return hipSuccess;
+    if (window < 1 || window > 64 * ATT_MAXC || (d & 1) || d > 256) return hipErrorInvalidValue;
+    const int nkmax = ATT_QT + window - 1;
+    size_t lds = ((size_t)2 * nkmax * (d + 1) + (size_t)ATT_QT * d + 4 * 64 * ATT_MAXC) * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    dim3 grid((T + ATT_QT - 1) / ATT_QT, nh, B);
+    const float scale = 1.0f / sqrtf((float)d);
+    hipError_t e;
+    if (dtype == Q3_BF16) {
+        auto k = swa_attention_kernel<bf16>;
+        if (lds > 48 * 1024 && (e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const bf16*)qkv, (bf16*)out, cos_t, sin_t, T, nh, nkv, d, window, scale);
+    } else {
+        auto k = swa_attention_kernel<float>;
+        if (lds > 48 * 1024 && (e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const float*)qkv, (float*)out, cos_t, sin_t, T, nh, nkv, d, window, scale);
+    }
+    return hipGetLastError();
+}
+
+hipError_t q3_launch_conv_out(const void* x, const float* w, float bias, float* wav, int B, int L, int C, int k, int dtype,
+                              hipStream_t s) {
+    if (B == 0 || L <= 0) return hipSuccess;
+    const int epc = dtype == Q3_BF16 ? 8 : 4;
+    if (C % epc) return hipErrorInvalidValue;
+    dim3 grid((L + 255) / 256, B);
+    size_t lds = (size_t)k * C * sizeof(float);
+    if (dtype == Q3_BF16)
+        hipLaunchKernelGGL(conv_out_kernel<bf16>, grid, dim3(256), lds, s, (const bf16*)x, w, bias, wav, L, C, k);
+    else
+        hipLaunchKernelGGL(conv_out_kernel<float>, grid, dim3(256), lds, s, (const float*)x, w, bias, wav, L, C, k);
+    return hipGetLastError();
+}
+
+hipError_t q3_launch_cast_to_f32(const void* x, float* y, long long n, int dtype, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    unsigned g = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    if (dtype == Q3_BF16)
+        hipLaunchKernelGGL(cast_to_f32_kernel<bf16>, dim3(g), dim3(256), 0, s, (const bf16*)x, y, n);
+    else
+        hipLaunchKernelGGL(cast_to_f32_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)x, y, n);
+    return hipGetLastError();
+}
+
+hipError_t q3_launch_cast_from_f32(const float* x, void* y, long long n, int dtype, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    unsigned g = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    if (dtype == Q3_BF16)
+        hipLaunchKernelGGL(cast_from_f32_kernel<bf16>, dim3(g), dim3(256), 0, s, x, (bf16*)y, n);
+    else
+        hipLaunchKernelGGL(cast_from_f32_kernel<float>, dim3(g), dim3(256), 0, s, x, (float*)y, n);
+    return hipGetLastError();
+}
+
+hipError_t q3_launch_snake(const void* x, void* y, const float* a, const float* invb, long long rows, int C, int dtype, hipStream_t s) {
+    long long n = rows * C;
+    if (n == 0) return hipSuccess;
+    unsigned g = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    if (dtype == Q3_BF16)
+        hipLaunchKernelGGL(snake_kernel<bf16>, dim3(g), dim3(256), 0, s, (const bf16*)x, (bf16*)y, a, invb, n, C);
+    else
+        hipLaunchKernelGGL(snake_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)x, (float*)y, a, invb, n, C);
+    return hipGetLastError();
+}

@@ -1,0 +1,312 @@
+"""Host side of the MI355X decode: `Decoder.decode(codes) -> (wavs, sr)`.
+
+Mirrors what the reference reaches through `Qwen3TTSModel.generate_voice_clone(...) -> (wavs, sr)`
+(reference server.py:245-251; `wavs[i]` is a 1-D float32 numpy array, `sr` 24000: server.py:379-389,
+API_GUIDE.md:152) and the tensor-level `forward` / `chunked_decode` of the sibling Code2Wav
+(transformers/models/qwen3_omni_moe/modeling_qwen3_omni_moe.py:3672-3696).  All arithmetic runs in
+libq3c.so (hand-written gfx950 kernels); torch is used for device memory and streams only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import DecoderConfig
+from .weights import validate_weights
+
+CodesLike = Union[torch.Tensor, np.ndarray, Dict[str, object], Sequence[object]]
+
+
+def rope_inv_freq(cfg: DecoderConfig) -> torch.Tensor:
+    """inv_freq = 1 / theta^(2i/d), computed by torch in fp32 exactly as the sibling's rotary embedding does
+    (modeling_qwen3_omni_moe.py:2419)."""
+    d = cfg.head_dim
+    return 1.0 / (cfg.rope_theta ** (torch.arange(0, d, 2, dtype=torch.float) / d))
+
+
+class Decoder:
+    """One decoder instance = one q3c context on one GPU."""
+
+    def __init__(self, cfg: DecoderConfig, weights: Dict[str, torch.Tensor], device: Union[str, torch.device] = "cuda:0",
+                 precision: str = "bf16", max_positions: int = 8192, max_frames_per_launch: int = 64 * 325):
+        if not torch.cuda.is_available():
+            raise RuntimeError("qwen3_tts_amd.Decoder needs a ROCm GPU (MI355X); there is no CPU fallback")
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.precision = precision
+        self.max_frames_per_launch = int(max_frames_per_launch)
+        self._lib = _lib.load()
+        self._ctx = C.c_void_p()
+        self._ws: Optional[torch.Tensor] = None
+        self._taps: Dict[int, torch.Tensor] = {}
+        validate_weights(cfg, weights)
+        qc = _lib.make_config(cfg, precision, max_positions)
+        with torch.cuda.device(self.device):
+            rc = self._lib.q3c_create(C.byref(qc), C.byref(self._ctx))
+            self._check(rc)
+            w = dict(weights)
+            w["rope.inv_freq"] = rope_inv_freq(cfg)
+            for name, t in w.items():
+                t = t.detach().to(device="cpu", dtype=torch.float32).contiguous()
+                shape = (C.c_int64 * t.dim())(*t.shape)
+                self._check(self._lib.q3c_load_weight(self._ctx, name.encode(), C.c_void_p(t.data_ptr()), shape, t.dim()))
+            self._check(self._lib.q3c_finalize(self._ctx))
+
+    # ------------------------------------------------------------------------------------------------
+    def _check(self, rc: int) -> None:
+        if rc != 0:
+            msg = self._lib.q3c_last_error(self._ctx).decode() if self._ctx else "no context"
+            if rc == -6:
+                raise IndexError(msg)              # torch's embedding raises IndexError for a bad index
+            raise _lib.Q3cError(rc, msg)
+
+    def close(self) -> None:
+        if getattr(self, "_ctx", None):
+            self._lib.q3c_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self) -> C.c_void_p:
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _workspace(self, batch: int, frames: int) -> torch.Tensor:
+        need = C.c_size_t()
+        self._check(self._lib.q3c_workspace_bytes(self._ctx, batch, frames, C.byref(need)))
+        if self._ws is None or self._ws.numel() < need.value:
+            self._ws = None
+            self._ws = torch.empty(need.value + 256, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def workspace_bytes(self, batch: int, frames: int) -> int:
+        need = C.c_size_t()
+        self._check(self._lib.q3c_workspace_bytes(self._ctx, batch, frames, C.byref(need)))
+        return int(need.value)
+
+    def _codes_tensor(self, codes) -> torch.Tensor:
+        codes = torch.as_tensor(codes)
+        if codes.dim() != 3 or codes.shape[1] != self.cfg.num_quantizers:
+            raise ValueError(f"Expected {self.cfg.num_quantizers} layer of codes, got {tuple(codes.shape)}")
+        return codes.to(device=self.device, dtype=torch.int64).contiguous()
+
+    # ------------------------------------------------------------------------------------------------
+    def forward(self, codes: torch.Tensor, check_codes: bool = False) -> torch.Tensor:
+        """codes [B, Q, T] int64 -> wav [B, 1, T*1920 - 555] float32 on the device, clamped to [-1, 1]."""
+        codes = self._codes_tensor(codes)
+        B, _, T = codes.shape
+        if T < 1 or B < 1:
+            raise ValueError("empty codes")
+        n = self.cfg.output_length(T)
+        wav = torch.empty((B, 1, n), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            ws = self._workspace(B, T)
+            base = (ws.data_ptr() + 255) // 256 * 256
+            self._check(self._lib.q3c_forward(self._ctx, C.c_void_p(codes.data_ptr()), B, T, C.c_void_p(wav.data_ptr()),
+                                              C.c_void_p(base), ws.numel() - (base - ws.data_ptr()), self._stream()))
+            if check_codes:
+                self._check(self._lib.q3c_check_errors(self._ctx, self._stream()))
+        return wav
+
+    __call__ = forward
+
+    def chunked_decode(self, codes: torch.Tensor, chunk_size: int = 300, left_context_size: int = 25) -> torch.Tensor:
+        """Same result layout as the sibling's chunked_decode (:3686-3696), but the chunks - which are independent,
+        each recomputing its own left context - are batched: all chunks of equal length go through one launch
+        sequence."""
+        codes = self._codes_tensor(codes)
+        B, _, T = codes.shape
+        up = self.cfg.total_upsample
+        plan = self.cfg.chunk_plan(T, chunk_size, left_context_size)
+        total = self.cfg.chunked_output_length(T, chunk_size, left_context_size)
+        out = torch.empty((B, 1, total), dtype=torch.float32, device=self.device)
+        offsets, off = [], 0
+        for s, e, ctx in plan:
+            offsets.append(off)
+            off += self.cfg.output_length(e - s) - ctx * up
+        groups: Dict[int, List[int]] = {}
+        for j, (s, e, _ctx) in enumerate(plan):
+            groups.setdefault(e - s, []).append(j)
+        for length, idxs in groups.items():
+            per = max(1, self.max_frames_per_launch // (length * B))
+            for i0 in range(0, len(idxs), per):
+                sub = idxs[i0:i0 + per]
+                stacked = torch.cat([codes[..., plan[j][0]:plan[j][1]] for j in sub], dim=0) if len(sub) > 1 \
+                    else codes[..., plan[sub[0]][0]:plan[sub[0]][1]]
+                wav = self.forward(stacked)
+                for n, j in enumerate(sub):
+                    ctx = plan[j][2]
+                    piece = wav[n * B:(n + 1) * B, :, ctx * up:]
+                    out[:, :, offsets[j]:offsets[j] + piece.shape[-1]] = piece
+        return out
+
+    def rvq_dequant(self, codes: torch.Tensor) -> torch.Tensor:
+        """Ordered fp32 gather-and-sum of each residual group: codes [B, Q, T] -> [B, T, G, codebook_dim]."""
+        codes = self._codes_tensor(codes)
+        B, _, T = codes.shape
+        G = 2 if self.cfg.num_quantizers > self.cfg.num_semantic_quantizers else 1
+        out = torch.empty((B, T, G, self.cfg.codebook_dim), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self._lib.q3c_rvq_dequant_f32(self._ctx, C.c_void_p(codes.data_ptr()), B, T, C.c_void_p(out.data_ptr()),
+                                                      self._stream()))
+            self._check(self._lib.q3c_check_errors(self._ctx, self._stream()))
+        return out
+
+    # ------------------------------------------------------------------------------------------------
+    def _normalize_items(self, encoded: CodesLike) -> List[torch.Tensor]:
+        """Accepts a [T, Q] / [Q, T] matrix, a [B, T, Q] / [B, Q, T] tensor, {"audio_codes": ...}, or a list of
+        those; returns per-utterance [Q, T_i] int64 tensors."""
+        Q = self.cfg.num_quantizers
+
+        def one(x) -> List[torch.Tensor]:
+            if isinstance(x, dict):
+                if "audio_codes" not in x:
+                    raise ValueError("dict input needs an 'audio_codes' entry")
+                return one(x["audio_codes"])
+            t = torch.as_tensor(x)
+            if t.dim() == 3:
+                out = []
+                for i in range(t.shape[0]):
+                    out += one(t[i])
+                return out
+            if t.dim() != 2:
+                raise ValueError(f"Expected 2-D or 3-D codes, got {tuple(t.shape)}")
+            if t.shape[1] == Q:            # [T, Q] (a square [Q, Q] matrix is read this way too)
+                t = t.t()
+            elif t.shape[0] != Q:
+                raise ValueError(f"Expected {Q} layer of codes, got {tuple(t.shape)}")
+            return [t.to(torch.int64)]
+
+        if isinstance(encoded, (list, tuple)):
+            items: List[torch.Tensor] = []
+            for e in encoded:
+                items += one(e)
+            return items
+        return one(encoded)
+
+    def decode(self, encoded: CodesLike, chunk_size: Optional[int] = None, left_context_size: Optional[int] = None,
+               pad_to: int = 25) -> Tuple[List[np.ndarray], int]:
+        """-> (list of float32 1-D numpy waveforms, 24000).  Utterances of different length are decoded together:
+        every (utterance, chunk) piece is padded with code 0 to a multiple of `pad_to` frames, pieces of equal padded
+        length share a launch sequence, and each piece keeps only its own prefix of the output (a frame never
+        influences samples that precede it by more than the fixed 555-sample lookahead)."""
+        cs = self.cfg.chunk_size if chunk_size is None else chunk_size
+        lc = self.cfg.left_context_size if left_context_size is None else left_context_size
+        items = self._normalize_items(encoded)
+        if not items:
+            return [], self.cfg.sample_rate
+        up, Q = self.cfg.total_upsample, self.cfg.num_quantizers
+        lengths, starts, jobs = [], [], []      # jobs: (item, s, e, ctx, offset_in_item)
+        total = 0
+        for i, c in enumerate(items):
+            T = int(c.shape[1])
+            if T < 1:
+                raise ValueError("empty code sequence")
+            n = self.cfg.chunked_output_length(T, cs, lc)
+            starts.append(total)
+            lengths.append(n)
+            total += n
+            off = 0
+            for s, e, ctx in self.cfg.chunk_plan(T, cs, lc):
+                jobs.append((i, s, e, ctx, off))
+                off += self.cfg.output_length(e - s) - ctx * up
+        out = torch.empty(total, dtype=torch.float32, device=self.device)
+        dev_items = [c.to(self.device) for c in items]
+        buckets: Dict[int, List[int]] = {}
+        for j, (_i, s, e, _ctx, _off) in enumerate(jobs):
+            buckets.setdefault(-(-(e - s) // pad_to) * pad_to, []).append(j)
+        for Lb, idxs in sorted(buckets.items()):
+            per = max(1, self.max_frames_per_launch // Lb)
+            for i0 in range(0, len(idxs), per):
+                sub = idxs[i0:i0 + per]
+                batch = torch.zeros((len(sub), Q, Lb), dtype=torch.int64, device=self.device)
+                for n, j in enumerate(sub):
+                    i, s, e, _ctx, _off = jobs[j]
+                    batch[n, :, : e - s] = dev_items[i][:, s:e]
+                wav = self.forward(batch)
+                for n, j in enumerate(sub):
+                    i, s, e, ctx, off = jobs[j]
+                    keep = self.cfg.output_length(e - s) - ctx * up
+                    out[starts[i] + off: starts[i] + off + keep] = wav[n, 0, ctx * up: ctx * up + keep]
+        with torch.cuda.device(self.device):
+            self._check(self._lib.q3c_check_errors(self._ctx, self._stream()))
+        host = out.cpu().numpy()
+        return [host[s:s + n].copy() for s, n in zip(starts, lengths)], self.cfg.sample_rate
+
+    # ------------------------------------------------------------------------------------------------
+    def set_tap(self, stage: int, elements: int) -> torch.Tensor:
+        """Debug/parity aid: capture a stage's output of the following forwards as fp32 (see include/q3c.h)."""
+        buf = torch.zeros(elements, dtype=torch.float32, device=self.device)
+        self._check(self._lib.q3c_set_tap(self._ctx, stage, C.c_void_p(buf.data_ptr()), elements))
+        self._taps[stage] = buf
+        return buf
+
+    def clear_taps(self) -> None:
+        for stage in list(self._taps):
+            self._lib.q3c_set_tap(self._ctx, stage, None, 0)
+        self._taps.clear()
+
+
+# ---- operator-level entry points (device fp32 tensors, channels-last) ------------------------------------
+def causal_conv1d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], dilation: int = 1,
+                  precision: str = "f32") -> torch.Tensor:
+    """x [B, L, Cin] (device fp32) -> [B, L, Cout]; weight [Cout, Cin, k] in the torch layout."""
+    lib = _lib.load()
+    B, L, cin = x.shape
+    cout, _, k = weight.shape
+    x = x.contiguous().float()
+    w = weight.detach().cpu().float().contiguous()
+    b = bias.detach().cpu().float().contiguous() if bias is not None else None
+    y = torch.empty((B, L, cout), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.q3c_causal_conv1d(C.c_void_p(x.data_ptr()), B, L, cin, cout, k, dilation, C.c_void_p(w.data_ptr()),
+                                   C.c_void_p(b.data_ptr()) if b is not None else None, C.c_void_p(y.data_ptr()),
+                                   _lib.PRECISION[precision], C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    if rc:
+        raise _lib.Q3cError(rc, "q3c_causal_conv1d failed")
+    return y
+
+
+def causal_trans_conv1d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int,
+                        precision: str = "f32") -> torch.Tensor:
+    """x [B, L, Cin] -> [B, (L-1)*s - k + 2s, Cout]; weight [Cin, Cout, k] in the torch layout."""
+    lib = _lib.load()
+    B, L, cin = x.shape
+    _, cout, k = weight.shape
+    lout = (L - 1) * stride - k + 2 * stride
+    x = x.contiguous().float()
+    w = weight.detach().cpu().float().contiguous()
+    b = bias.detach().cpu().float().contiguous() if bias is not None else None
+    y = torch.empty((B, max(lout, 0), cout), dtype=torch.float32, device=x.device)
+    if lout <= 0:
+        return y
+    with torch.cuda.device(x.device):
+        rc = lib.q3c_causal_tconv1d(C.c_void_p(x.data_ptr()), B, L, cin, cout, k, stride, C.c_void_p(w.data_ptr()),
+                                    C.c_void_p(b.data_ptr()) if b is not None else None, C.c_void_p(y.data_ptr()),
+                                    _lib.PRECISION[precision], C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    if rc:
+        raise _lib.Q3cError(rc, "q3c_causal_tconv1d failed")
+    return y
+
+
+def snake_beta(x: torch.Tensor, alpha: torch.Tensor, beta: torch.Tensor, eps: float = 1e-9) -> torch.Tensor:
+    """x [..., C] (device fp32, channels-last)."""
+    lib = _lib.load()
+    Cn = x.shape[-1]
+    x = x.contiguous().float()
+    a = alpha.detach().cpu().float().contiguous()
+    b = beta.detach().cpu().float().contiguous()
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = lib.q3c_snake_beta(C.c_void_p(x.data_ptr()), x.numel() // Cn, Cn, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()),
+                                eps, C.c_void_p(y.data_ptr()), C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    if rc:
+        raise _lib.Q3cError(rc, "q3c_snake_beta failed")
+    return y

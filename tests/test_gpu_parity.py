@@ -1,0 +1,201 @@
+"""GPU parity tests: the HIP path (through the C ABI in libq3c.so) against the CPU oracle and the golden
+fixtures.  Bars: RVQ gather-and-sum bit-exact in fp32; fp32 waveform max-abs <= 1e-3 and SNR >= 60 dB;
+the bf16 bound is stated in `BF16_*` below (measured with the variance-preserving synthetic weights)."""
+import numpy as np
+import pytest
+import torch
+
+import qwen3_tts_amd as q3
+import decoder_oracle as oracle
+from gpu_util import format_report, max_abs, snr_db, stage_report
+
+pytestmark = pytest.mark.gpu
+
+F32_MAX_ABS, F32_SNR_DB = 1e-3, 60.0
+BF16_MAX_ABS, BF16_SNR_DB = 0.15, 25.0      # stated bf16 tolerance (storage and MFMA operands in bf16, ~45 layers deep)
+
+
+def _decoder(cfg, w, precision):
+    from qwen3_tts_amd.decoder import Decoder
+    return Decoder(cfg, w, device="cuda:0", precision=precision)
+
+
+def _weights(meta):
+    cfg = q3.DecoderConfig.from_dict(meta["config"])
+    return cfg, q3.synthetic_weights(cfg, seed=meta["weight_seed"])
+
+
+# ---- RVQ: bit-exact ------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["rvq_tiny", "rvq_q16", "rvq_sem2"])
+def test_rvq_bit_exact_vs_golden(golden, name):
+    meta, a = golden(name)
+    cfg, w = _weights(meta)
+    dec = _decoder(cfg, w, "f32")
+    got = dec.rvq_dequant(torch.from_numpy(a["codes"])).cpu().numpy()            # [B, T, G, D]
+    want = np.ascontiguousarray(a["group_sums"].transpose(0, 2, 1, 3))            # fixture is [B, G, T, D]
+    assert got.dtype == np.float32
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_rvq_bit_exact_full_size():
+    """Full-size code books (16 x 2048 x 256), uniform codes, against the oracle's ordered sum."""
+    cfg = q3.tiny_config(codebook_size=2048, num_quantizers=16, codebook_dim=256, rvq_out_dim=32)
+    w = q3.synthetic_weights(cfg, seed=2)
+    codes = q3.random_codes(cfg, 3, 301, seed=8)
+    _, sums = oracle.rvq_dequant(cfg, w, codes)
+    want = torch.stack(sums, 2).numpy()                                           # [B, T, G, D]
+    got = _decoder(cfg, w, "bf16").rvq_dequant(codes).cpu().numpy()               # the dequantiser is fp32 in every mode
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_rvq_negative_zero_and_bad_code():
+    cfg = q3.tiny_config()
+    w = q3.synthetic_weights(cfg, seed=1)
+    w["quantizer.semantic.layers.0.embed_sum"][3, :] = -0.0
+    dec = _decoder(cfg, w, "f32")
+    codes = torch.full((1, cfg.num_quantizers, 2), 3, dtype=torch.int64)
+    out = dec.rvq_dequant(codes).cpu()
+    assert (out[0, :, 0, :].view(torch.int32) == 0).all()                          # +0.0, not -0.0
+    codes[0, 1, 1] = cfg.codebook_size
+    with pytest.raises(IndexError):
+        dec.rvq_dequant(codes)
+    dec.rvq_dequant(torch.zeros_like(codes))                                       # flag was cleared
+
+
+# ---- single operators against the sibling fixtures ------------------------------------------------------
+@pytest.mark.parametrize("precision,atol", [("f32", 2e-5), ("bf16", 6e-2)])
+def test_operators_vs_golden(golden, precision, atol):
+    from qwen3_tts_amd import decoder as D
+    meta, a = golden("primitives")
+    dev = torch.device("cuda:0")
+    cl = lambda k: torch.from_numpy(a[k]).permute(0, 2, 1).contiguous().to(dev)   # fixtures are [B, C, L]
+    worst = 0.0
+    for c in meta["cases"]:
+        tag = c["tag"]
+        if c["kind"] == "causal_conv" and c["groups"] == 1:
+            y = D.causal_conv1d(cl(tag + ".x"), torch.from_numpy(a[tag + ".w"]), torch.from_numpy(a[tag + ".b"]), c["dilation"], precision)
+        elif c["kind"] == "trans_conv":
+            y = D.causal_trans_conv1d(cl(tag + ".x"), torch.from_numpy(a[tag + ".w"]), torch.from_numpy(a[tag + ".b"]), c["stride"], precision)
+        elif c["kind"] == "snake" and precision == "f32":
+            y = D.snake_beta(cl(tag + ".x"), torch.from_numpy(a[tag + ".alpha"]), torch.from_numpy(a[tag + ".beta"]))
+        else:
+            continue
+        want = a[tag + ".y"].transpose(0, 2, 1)
+        got = y.cpu().numpy()
+        assert got.shape == want.shape, (tag, got.shape, want.shape)
+        err = max_abs(want, got)
+        worst = max(worst, err)
+        assert err <= atol, f"{tag}: max|err| {err:.3e} ({precision})"
+    print(f"operators {precision}: worst max|err| {worst:.3e}")
+
+
+# ---- whole decode ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["decoder_tiny", "decoder_gqa"])
+def test_forward_fp32_vs_sibling_golden(golden, name):
+    """mean-embedding front end, fp32 path, against the sibling Code2Wav outputs stored in the fixture."""
+    meta, a = golden(name)
+    cfg, w = _weights(meta)
+    dec = _decoder(cfg, w, "f32")
+    for c in meta["cases"]:
+        T = c["T"]
+        codes = torch.from_numpy(a[f"T{T}.codes"])
+        if c.get("chunked"):
+            wav = dec.chunked_decode(codes, 300, 25)[0, 0].cpu().numpy()
+            assert wav.shape[0] == c["length"]
+            e1 = max_abs(a[f"T{T}.wav_stride7"], wav[3::7])
+            s = c["seam"]
+            e2 = max_abs(a[f"T{T}.wav_seam"], wav[s - 2048: s + 2048])
+            assert max(e1, e2) <= F32_MAX_ABS, (e1, e2)
+            assert snr_db(a[f"T{T}.wav_stride7"], wav[3::7]) >= F32_SNR_DB
+        else:
+            wav = dec.forward(codes)[:, 0].cpu().numpy()
+            want = a[f"T{T}.wav"]
+            assert wav.shape[1] == c["length"]
+            got = wav[-want.shape[0]:]
+            err, snr = max_abs(want, got), snr_db(want, got)
+            if not (err <= F32_MAX_ABS and snr >= F32_SNR_DB):
+                rows, _, _ = stage_report(dec, cfg, w, codes)
+                pytest.fail(f"{name} T={T}: max|err| {err:.3e} snr {snr:.1f} dB\n" + format_report(rows))
+
+
+@pytest.mark.parametrize("T", [1, 2, 40, 73])
+def test_forward_fp32_split_rvq_vs_oracle(T):
+    cfg = q3.tiny_config()
+    w = q3.synthetic_weights(cfg, seed=5)
+    dec = _decoder(cfg, w, "f32")
+    codes = q3.random_codes(cfg, 2, T, seed=T)
+    rows, ref, wav = stage_report(dec, cfg, w, codes)
+    print(f"fp32 split_rvq T={T}\n" + format_report(rows))
+    assert wav.shape == ref.shape == (2, 1, cfg.output_length(T))
+    assert rows[-1][1] <= F32_MAX_ABS and rows[-1][2] >= F32_SNR_DB, format_report(rows)
+    assert float(wav.abs().max()) <= 1.0
+
+
+def test_forward_bf16_tolerance():
+    cfg = q3.tiny_config()
+    w = q3.synthetic_weights(cfg, seed=5)
+    dec = _decoder(cfg, w, "bf16")
+    codes = q3.random_codes(cfg, 2, 40, seed=40)
+    rows, ref, wav = stage_report(dec, cfg, w, codes)
+    print("bf16 tiny T=40\n" + format_report(rows))
+    assert rows[-1][1] <= BF16_MAX_ABS and rows[-1][2] >= BF16_SNR_DB, format_report(rows)
+
+
+def test_forward_wide_channels_fp32_and_bf16():
+    """Channel widths that use every tile configuration of the contraction kernel (96-wide and 128-wide tiles,
+    64- and 128-byte K rows), still small enough for the CPU oracle."""
+    cfg = q3.tiny_config(latent_dim=128, hidden_size=128, num_attention_heads=4, head_dim=32, intermediate_size=256,
+                         decoder_dim=1536, codebook_dim=32, rvq_out_dim=64, num_hidden_layers=1)
+    w = q3.synthetic_weights(cfg, seed=6)
+    codes = q3.random_codes(cfg, 1, 6, seed=3)
+    dec = _decoder(cfg, w, "f32")
+    rows, ref, wav = stage_report(dec, cfg, w, codes)
+    print("fp32 wide\n" + format_report(rows))
+    assert rows[-1][1] <= F32_MAX_ABS and rows[-1][2] >= F32_SNR_DB, format_report(rows)
+    dec16 = _decoder(cfg, w, "bf16")
+    rows16, _, _ = stage_report(dec16, cfg, w, codes)
+    print("bf16 wide\n" + format_report(rows16))
+    assert rows16[-1][1] <= BF16_MAX_ABS and rows16[-1][2] >= BF16_SNR_DB, format_report(rows16)
+
+
+def test_decode_wrapper_ragged_vs_oracle():
+    """decode() over utterances of different length (one crossing the 300-frame chunk edge) == per-item oracle."""
+    cfg = q3.tiny_config()
+    w = q3.synthetic_weights(cfg, seed=5)
+    dec = _decoder(cfg, w, "f32")
+    items = [q3.random_codes(cfg, 1, T, seed=10 + T)[0].t().contiguous() for T in (3, 17, 40, 301)]
+    wavs, sr = dec.decode([{"audio_codes": items[0]}, items[1], items[2].t(), items[3]])
+    want, sr2 = oracle.decode(cfg, w, items)
+    assert sr == sr2 == 24000
+    for g, r in zip(wavs, want):
+        assert g.dtype == np.float32 and g.shape == r.shape
+        assert max_abs(r, g) <= F32_MAX_ABS and snr_db(r, g) >= F32_SNR_DB
+
+
+def test_batch_rows_are_independent():
+    """An utterance decodes to the same bits alone, in a batch, and zero-padded (what ragged batching relies on)."""
+    cfg = q3.tiny_config()
+    w = q3.synthetic_weights(cfg, seed=5)
+    dec = _decoder(cfg, w, "bf16")
+    codes = q3.random_codes(cfg, 3, 20, seed=2)
+    full = dec.forward(codes).cpu()
+    alone = dec.forward(codes[1:2]).cpu()
+    assert torch.equal(full[1:2], alone)
+    padded = torch.zeros(1, cfg.num_quantizers, 33, dtype=torch.int64)
+    padded[:, :, :20] = codes[1:2]
+    pref = dec.forward(padded).cpu()[..., : alone.shape[-1]]
+    assert torch.equal(pref, alone)
+
+
+def test_errors():
+    cfg = q3.tiny_config()
+    w = q3.synthetic_weights(cfg, seed=5)
+    dec = _decoder(cfg, w, "f32")
+    with pytest.raises(ValueError):
+        dec.forward(torch.zeros(1, cfg.num_quantizers + 1, 4, dtype=torch.int64))
+    bad = dict(w)
+    bad.pop("decoder.0.conv.bias")
+    with pytest.raises(ValueError):
+        _decoder(cfg, bad, "f32")
+    with pytest.raises(IndexError):
+        dec.decode(torch.full((4, cfg.num_quantizers), cfg.codebook_size, dtype=torch.int64))
