@@ -1,0 +1,162 @@
+"""Benchmark of the codec-decode hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A step = one chunked decode of the batch `BASELINE.json.configs[1]` names: 64 utterances x 30 s (375 code frames
+each; chunks of 300 + 25 frames of recomputed left context, the reference's chunked_decode semantics), bf16 storage
+and MFMA operands with fp32 accumulation, synthetic uniform codes already resident in HBM, seeded random-init weights
+of the flagship architecture.  With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank decodes
+its own 64 x 30 s batch (weak scaling, no collective on the data path); the value is all ranks' audio-seconds over
+the slowest rank's time.  Rank 0 prints ONE JSON line.
+
+Besides the contract fields the line carries
+  roofline      the dominant kernel (by summed time): algorithmic FLOPs of its launches / their summed duration,
+                both measured in this run by HIP events on the launch stream, against the dense bf16 MFMA peak;
+  cpu_baseline  the CPU restatement of the decode (oracle/, fp32 torch) timed on this host's cores on a bounded
+                sample (N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import qwen3_tts_amd as q3  # noqa: E402
+from qwen3_tts_amd.decoder import Decoder  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(cfg, weights, frames: int, threads: int) -> dict:
+    """The oracle (a port: the reference's own decode is in a package that is not installed) on the host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import decoder_oracle as oracle
+    torch.set_num_threads(threads)
+    codes = q3.random_codes(cfg, 1, frames, seed=0)
+    t0 = time.perf_counter()
+    wav = oracle.forward(cfg, weights, codes)
+    dt = time.perf_counter() - t0
+    assert wav.shape[-1] == cfg.output_length(frames)
+    return {"value": round(frames / cfg.frame_rate / dt, 4), "unit": "audio-sec/sec", "cores": threads, "kind": "port",
+            "sample": f"1 utterance x {frames / cfg.frame_rate:.1f} s ({frames} frames), fp32 torch CPU restatement of the decode, "
+                      f"one un-chunked forward, 1 timed run, no warm-up ({dt:.1f} s)"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--seconds", type=float, default=30.0)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--unchunked", action="store_true", help="one forward over all frames instead of chunked_decode")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=125)
+    ap.add_argument("--tiny", action="store_true", help="tiny architecture (plumbing check only; not a valid result)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and distributed:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    device = torch.device("cuda", local_rank)
+
+    cfg = q3.tiny_config() if args.tiny else q3.flagship_config()
+    weights = q3.synthetic_weights(cfg, seed=0)
+    frames = int(round(args.seconds * cfg.frame_rate))
+    dec = Decoder(cfg, weights, device=device, precision=args.precision, max_frames_per_launch=args.batch * 325)
+    codes = q3.random_codes(cfg, args.batch, frames, seed=1 + rank).to(device)
+
+    def step():
+        return dec.forward(codes) if args.unchunked else dec.chunked_decode(codes, cfg.chunk_size, cfg.left_context_size)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        wav = step()
+    barrier()
+    dec.profile(True)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(torch.cuda.current_stream(device))
+    for _ in range(args.steps):
+        wav = step()
+    ev1.record(torch.cuda.current_stream(device))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = dec.profile_read()
+    dec.profile(False)
+    expect = cfg.output_length(frames) if args.unchunked else cfg.chunked_output_length(frames)
+    assert wav.shape == (args.batch, 1, expect), wav.shape
+    assert bool(torch.isfinite(wav).all()) and float(wav.abs().max()) <= 1.0
+
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    audio_sec = world * args.batch * frames / cfg.frame_rate * args.steps
+    value = audio_sec / elapsed
+
+    out = None
+    if rank == 0:
+        total_ms = sum(p["ms"] for p in prof) or 1.0
+        prof.sort(key=lambda p: -p["ms"])
+        dom = prof[0]
+        if dom["flops"] > 0:
+            achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": dom["launches"] // args.steps,
+                    "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
+                    "share_of_gpu_time": round(dom["ms"] / total_ms, 3)}
+        else:
+            achieved = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None}
+        flops_frame = cfg.flops_per_frame()
+        whole = value * cfg.frame_rate * flops_frame / 1e12      # algorithmic TFLOP/s of the whole path, all ranks
+        out = {
+            "metric": "audio-sec decoded/sec", "value": round(value, 1), "unit": "audio-sec/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"batch {args.batch} x {args.seconds:g} s utterances per GPU "
+                                   f"({'one un-chunked forward' if args.unchunked else 'chunked decode 300+25'}), "
+                                   f"{'tiny' if args.tiny else 'flagship'} architecture, random-init weights, uniform codes",
+                       "frames_per_utterance": frames, "gflop_per_audio_sec": round(flops_frame * cfg.frame_rate / 1e9, 2),
+                       "whole_path_tflops_per_gpu": round(whole / world, 1),
+                       "whole_path_frac_of_bf16_peak": round(whole / world / PEAK_BF16_TFLOPS, 4),
+                       "gpu_event_ms_per_step": round(ev0.elapsed_time(ev1) / args.steps, 3)},
+            "roofline": roof,
+            "kernels": [{"kernel": p["kernel"], "launches": p["launches"] // args.steps, "ms_per_step": round(p["ms"] / args.steps, 3),
+                         **({"tflops": round(p["flops"] / (p["ms"] * 1e-3) / 1e12, 1)} if p["flops"] else
+                            {"gbs": round(p["bytes"] / (p["ms"] * 1e-3) / 1e9, 1)})} for p in prof[:8]],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+            out["cpu_baseline"] = cpu_baseline(cfg, weights, args.cpu_frames if not args.tiny else 12, threads)
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -108,6 +108,19 @@ int q3c_check_errors(q3c_ctx* ctx, void* hip_stream);
 /* Capture a stage output of the following q3c_forward calls as fp32 into caller memory (NULL removes the tap). */
 int q3c_set_tap(q3c_ctx* ctx, int32_t stage, float* dev_buffer, size_t capacity_elements);
 
+/* -- per-kernel timing (no counterpart in the reference; used by bench.py for the roofline figures) -----------
+ * While enabled, every kernel launch of q3c_forward is bracketed by a pair of HIP events on the caller's stream.
+ * q3c_profile_read synchronises those events and returns, per kernel, the number of launches, the summed duration,
+ * and the ALGORITHMIC work of those launches: flops = 2*B*M*N*K*taps of the layer (no tile padding), bytes = the
+ * tensors a memory-bound kernel must read and write once. */
+typedef struct q3c_profile_entry {
+    char kernel[64];
+    int64_t launches;
+    double ms, flops, bytes;
+} q3c_profile_entry;
+int q3c_profile_enable(q3c_ctx* ctx, int32_t on);
+int q3c_profile_read(q3c_ctx* ctx, q3c_profile_entry* out, int32_t capacity, int32_t* count);
+
 /* -- single operators (host weights in the PyTorch layout are repacked and uploaded per call: meant for
  *    operator-level parity tests and integration bring-up, not for the serving loop; they synchronise) ------
  * x / y are DEVICE fp32, channels-last.  precision picks the MFMA operand type as in q3c_config. */

@@ -18,7 +18,13 @@ STAGE_RVQ_OUT, STAGE_TRANSFORMER_IN, STAGE_TRANSFORMER_OUT, STAGE_UPSAMPLE0, STA
 
 EXPORTS = ["q3c_create", "q3c_destroy", "q3c_last_error", "q3c_version", "q3c_load_weight", "q3c_finalize",
            "q3c_workspace_bytes", "q3c_output_length", "q3c_forward", "q3c_rvq_dequant_f32", "q3c_check_errors",
-           "q3c_set_tap", "q3c_causal_conv1d", "q3c_causal_tconv1d", "q3c_snake_beta"]
+           "q3c_set_tap", "q3c_causal_conv1d", "q3c_causal_tconv1d", "q3c_snake_beta", "q3c_profile_enable",
+           "q3c_profile_read"]
+
+
+class Q3cProfileEntry(C.Structure):
+    _fields_ = [("kernel", C.c_char * 64), ("launches", C.c_int64), ("ms", C.c_double), ("flops", C.c_double),
+                ("bytes", C.c_double)]
 
 
 class Q3cConfig(C.Structure):
@@ -75,6 +81,8 @@ def load() -> C.CDLL:
     lib.q3c_causal_conv1d.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp]
     lib.q3c_causal_tconv1d.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp]
     lib.q3c_snake_beta.argtypes = [vp, C.c_int64, i32, vp, vp, C.c_float, vp, vp]
+    lib.q3c_profile_enable.argtypes = [vp, i32]
+    lib.q3c_profile_read.argtypes = [vp, C.POINTER(Q3cProfileEntry), i32, C.POINTER(i32)]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("q3c_destroy", "q3c_last_error", "q3c_version"):

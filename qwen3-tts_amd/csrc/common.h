@@ -40,6 +40,7 @@ enum Q3Dtype : int { Q3_F32 = 0, Q3_BF16 = 1 };
 
 // ---- launchers (each returns hipError_t of the launch) -------------------------------------------
 hipError_t q3_launch_convgemm(const ConvGemmArgs& a, int in_dtype, int out_dtype, hipStream_t s);
+const char* q3_convgemm_variant(const ConvGemmArgs& a, int in_dtype, int out_dtype);   // name of the instantiation that would run
 
 hipError_t q3_launch_rvq_gather_sum(const long long* codes, int B, int Q, int T, int bins, int D,
                                     const float* const* tables_dev /*[Q] device array of table pointers*/,

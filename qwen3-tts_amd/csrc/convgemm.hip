@@ -307,16 +307,32 @@ hipError_t launch_cfg(const ConvGemmArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// tile shape selection: 0 = 256x96 tile / 64-byte K rows, 1 = 128x128 / 128-byte, 2 = 128x128 / 64-byte
+int pick_shape(const ConvGemmArgs& a, size_t elem) {
+    const bool wide_k = ((size_t)a.K * elem) % 128 == 0;
+    const bool use_96 = (a.act != Q3_ACT_SWIGLU) && (a.N % 128 != 0) && (a.N % 96 == 0) && a.N < 512;
+    return use_96 ? 0 : (wide_k ? 1 : 2);
+}
+
 template <typename TA, typename TO>
 hipError_t launch_typed(const ConvGemmArgs& a, hipStream_t s) {
-    const bool wide_k = ((size_t)a.K * sizeof(TA)) % 128 == 0;
-    const bool use_96 = (a.act != Q3_ACT_SWIGLU) && (a.N % 128 != 0) && (a.N % 96 == 0) && a.N < 512;
-    if (use_96) return launch_cfg<TA, TO, 4, 1, 2, 3, 64>(a, s);
-    if (wide_k) return launch_cfg<TA, TO, 2, 2, 2, 2, 128>(a, s);
-    return launch_cfg<TA, TO, 2, 2, 2, 2, 64>(a, s);
+    switch (pick_shape(a, sizeof(TA))) {
+        case 0: return launch_cfg<TA, TO, 4, 1, 2, 3, 64>(a, s);
+        case 1: return launch_cfg<TA, TO, 2, 2, 2, 2, 128>(a, s);
+        default: return launch_cfg<TA, TO, 2, 2, 2, 2, 64>(a, s);
+    }
 }
 
 }  // namespace
+
+const char* q3_convgemm_variant(const ConvGemmArgs& a, int in_dtype, int out_dtype) {
+    static const char* names[3][3] = {
+        {"convgemm<f32,f32,256x96,k64B>", "convgemm<f32,f32,128x128,k128B>", "convgemm<f32,f32,128x128,k64B>"},
+        {"convgemm<bf16,bf16,256x96,k64B>", "convgemm<bf16,bf16,128x128,k128B>", "convgemm<bf16,bf16,128x128,k64B>"},
+        {"convgemm<f32,bf16,256x96,k64B>", "convgemm<f32,bf16,128x128,k128B>", "convgemm<f32,bf16,128x128,k64B>"}};
+    const int t = (in_dtype == Q3_F32 && out_dtype == Q3_F32) ? 0 : (in_dtype == Q3_BF16 ? 1 : 2);
+    return names[t][pick_shape(a, in_dtype == Q3_BF16 ? 2 : 4)];
+}
 
 hipError_t q3_launch_convgemm(const ConvGemmArgs& a, int in_dtype, int out_dtype, hipStream_t s) {
     if (a.M <= 0 || a.B <= 0) return hipSuccess;

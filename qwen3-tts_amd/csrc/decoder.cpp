@@ -64,12 +64,30 @@ struct q3c_ctx {
     int* err_flag = nullptr;
     std::map<int, std::pair<float*, size_t>> taps;
 
+    // per-kernel timing
+    struct ProfRec { hipEvent_t a, b; const char* name; double flops, bytes; };
+    bool profiling = false;
+    std::vector<ProfRec> prof;
+    std::vector<hipEvent_t> event_pool;
+
     int total_upsample = 1, trim = 0;
 };
 
 namespace {
 
 int fail(const q3c_ctx* c, int code, const std::string& msg) { if (c) c->err = msg; return code; }
+
+// Brackets one launch with events when profiling is on.
+struct ProfScope {
+    q3c_ctx* c; hipStream_t s; q3c_ctx::ProfRec r{}; bool on;
+    ProfScope(q3c_ctx* c_, hipStream_t s_, const char* name, double flops, double bytes) : c(c_), s(s_), on(c_->profiling) {
+        if (!on) return;
+        auto get = [&]() { hipEvent_t e; if (!c->event_pool.empty()) { e = c->event_pool.back(); c->event_pool.pop_back(); } else (void)hipEventCreate(&e); return e; };
+        r.a = get(); r.b = get(); r.name = name; r.flops = flops; r.bytes = bytes;
+        (void)hipEventRecord(r.a, s);
+    }
+    ~ProfScope() { if (on) { (void)hipEventRecord(r.b, s); c->prof.push_back(r); } }
+};
 
 #define HIPCHK(ctx, expr)                                                                              \
     do {                                                                                               \
@@ -232,6 +250,7 @@ int gemm(q3c_ctx* c, const GemmW& g, const void* X, int B, int L_in, void* Y, in
     if (g.taps == 1 && M == L_in) {      // no halo: batch items are just more rows
         a.M = B * M; a.L_in = B * L_in; a.B = 1;
     }
+    ProfScope ps(c, s, c->profiling ? q3_convgemm_variant(a, g.in_dtype, out_dtype) : "", 2.0 * a.B * a.M * (double)a.N * a.K * a.taps, 0.0);
     hipError_t e = q3_launch_convgemm(a, g.in_dtype, out_dtype, s);
     if (e != hipSuccess) return fail(c, Q3C_ERR_HIP, std::string("convgemm launch: ") + hipGetErrorString(e));
     return 0;
@@ -293,6 +312,12 @@ int tap_out(q3c_ctx* c, int stage, const void* p, size_t n, hipStream_t s) {
         hipError_t _e = (expr);                                                                      \
         if (_e != hipSuccess) return fail(ctx, Q3C_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
     } while (0)
+// a memory-bound launch with its algorithmic byte count
+#define LAUNCH_B(ctx, stream, name, bytes, expr)                 \
+    do {                                                         \
+        ProfScope _ps(ctx, stream, name, 0.0, (double)(bytes));  \
+        LAUNCH(ctx, expr);                                       \
+    } while (0)
 #define TRY(expr) do { int _r = (expr); if (_r) return _r; } while (0)
 
 int validate_config(q3c_ctx* c) {
@@ -350,6 +375,8 @@ int q3c_create(const q3c_config* cfg, q3c_ctx** out) {
 
 void q3c_destroy(q3c_ctx* c) {
     if (!c) return;
+    for (auto& r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     for (void* p : c->allocs) (void)hipFree(p);
     delete c;
 }
@@ -591,11 +618,13 @@ int q3c_forward(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, float* w
 
     // ---- front end -> x0 [B,T,Lt] in bufA ----
     if (k.frontend == Q3C_FRONTEND_MEAN_EMBEDDING) {
-        LAUNCH(c, q3_launch_mean_embedding((const long long*)codes, B, k.num_quantizers, T, k.codebook_size, H, c->emb_table, bufA, dt,
-                                           c->err_flag, s));
+        LAUNCH_B(c, s, "mean_embedding", fr * ((size_t)k.num_quantizers * (8 + H * 4) + H * es),
+                 q3_launch_mean_embedding((const long long*)codes, B, k.num_quantizers, T, k.codebook_size, H, c->emb_table, bufA, dt,
+                                          c->err_flag, s));
     } else {
-        LAUNCH(c, q3_launch_rvq_gather_sum((const long long*)codes, B, k.num_quantizers, T, k.codebook_size, k.codebook_dim,
-                                           c->tables_dev, c->group_start_dev, c->G, S, c->err_flag, s));
+        LAUNCH_B(c, s, "rvq_gather_sum", fr * ((size_t)k.num_quantizers * (8 + k.codebook_dim * 4) + (size_t)c->G * k.codebook_dim * 4),
+                 q3_launch_rvq_gather_sum((const long long*)codes, B, k.num_quantizers, T, k.codebook_size, k.codebook_dim,
+                                          c->tables_dev, c->group_start_dev, c->G, S, c->err_flag, s));
         TRY(gemm(c, c->rvq_proj, S, B, T, Qb, T, dt, GemmOpts{}, s));
         TRY(tap_out(c, Q3C_STAGE_RVQ_OUT, Qb, fr * k.rvq_out_dim, s));
         TRY(gemm(c, c->pre_conv, Qb, B, T, bufA, T, dt, GemmOpts{}, s));
@@ -611,19 +640,20 @@ int q3c_forward(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, float* w
     void* mlp = (char*)att + align_up(fr * qd * es);
     for (int l = 0; l < k.num_hidden_layers; ++l) {
         const Layer& y = c->layers[l];
-        LAUNCH(c, q3_launch_rmsnorm(x, y.ln1, nrm, (long long)fr, H, k.rms_norm_eps, dt, s));
+        LAUNCH_B(c, s, "rmsnorm", 2 * fr * H * es, q3_launch_rmsnorm(x, y.ln1, nrm, (long long)fr, H, k.rms_norm_eps, dt, s));
         TRY(gemm(c, y.qkv, nrm, B, T, qkv, T, dt, GemmOpts{}, s));
-        LAUNCH(c, q3_launch_swa_attention(qkv, att, c->cos_t, c->sin_t, B, T, k.num_attention_heads, k.num_key_value_heads, k.head_dim,
-                                          k.sliding_window, dt, s));
+        LAUNCH_B(c, s, "swa_attention", fr * (size_t)(2 * qd + 2 * kvd) * es,
+                 q3_launch_swa_attention(qkv, att, c->cos_t, c->sin_t, B, T, k.num_attention_heads, k.num_key_value_heads, k.head_dim,
+                                         k.sliding_window, dt, s));
         GemmOpts o1; o1.scale = y.ls_attn; o1.R = x;
         TRY(gemm(c, y.o, att, B, T, x, T, dt, o1, s));
-        LAUNCH(c, q3_launch_rmsnorm(x, y.ln2, nrm, (long long)fr, H, k.rms_norm_eps, dt, s));
+        LAUNCH_B(c, s, "rmsnorm", 2 * fr * H * es, q3_launch_rmsnorm(x, y.ln2, nrm, (long long)fr, H, k.rms_norm_eps, dt, s));
         GemmOpts o2; o2.act = Q3_ACT_SWIGLU;
         TRY(gemm(c, y.gu, nrm, B, T, mlp, T, dt, o2, s));
         GemmOpts o3; o3.scale = y.ls_mlp; o3.R = x;
         TRY(gemm(c, y.down, mlp, B, T, x, T, dt, o3, s));
     }
-    LAUNCH(c, q3_launch_rmsnorm(x, c->final_norm, nrm, (long long)fr, H, k.rms_norm_eps, dt, s));
+    LAUNCH_B(c, s, "rmsnorm", 2 * fr * H * es, q3_launch_rmsnorm(x, c->final_norm, nrm, (long long)fr, H, k.rms_norm_eps, dt, s));
     void* cur; void* other;
     if (k.io_proj) { TRY(gemm(c, c->out_proj, nrm, B, T, x, T, dt, GemmOpts{}, s)); cur = x; other = nrm; }
     else { cur = nrm; other = x; }
@@ -638,7 +668,8 @@ int q3c_forward(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, float* w
         const size_t rows = (size_t)B * L;
         void* d = bufC;
         void* pw = bufC + align_up(rows * Lt * es);
-        LAUNCH(c, q3_launch_dwconv_ln(other, u.dw_w, u.dw_b, u.ln_w, u.ln_b, d, B, L, Lt, 7, k.convnext_eps, dt, s));
+        LAUNCH_B(c, s, "dwconv_ln", 2 * rows * Lt * es,
+                 q3_launch_dwconv_ln(other, u.dw_w, u.dw_b, u.ln_w, u.ln_b, d, B, L, Lt, 7, k.convnext_eps, dt, s));
         GemmOpts g1; g1.act = Q3_ACT_GELU;
         TRY(gemm(c, u.pw1, d, B, L, pw, L, dt, g1, s));
         GemmOpts g2; g2.scale = u.gamma; g2.R = other;
@@ -674,7 +705,32 @@ int q3c_forward(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, float* w
         std::swap(cur, other);
         TRY(tap_out(c, Q3C_STAGE_BLOCK0 + (int)i, cur, (size_t)B * L * ch, s));
     }
-    LAUNCH(c, q3_launch_conv_out(cur, c->out_w, c->out_b, wav, B, L, ch, c->out_k, dt, s));
+    LAUNCH_B(c, s, "conv_out_clamp", (size_t)B * L * (ch * es + 4), q3_launch_conv_out(cur, c->out_w, c->out_b, wav, B, L, ch, c->out_k, dt, s));
+    return 0;
+}
+
+int q3c_profile_enable(q3c_ctx* c, int32_t on) {
+    if (!c) return Q3C_ERR_INVALID_ARGUMENT;
+    for (auto& r : c->prof) { c->event_pool.push_back(r.a); c->event_pool.push_back(r.b); }
+    c->prof.clear();
+    c->profiling = on != 0;
+    return 0;
+}
+
+int q3c_profile_read(q3c_ctx* c, q3c_profile_entry* out, int32_t cap, int32_t* count) {
+    if (!c || !out || !count || cap < 1) return Q3C_ERR_INVALID_ARGUMENT;
+    std::map<std::string, q3c_profile_entry> agg;
+    for (auto& r : c->prof) {
+        HIPCHK(c, hipEventSynchronize(r.b));
+        float ms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&ms, r.a, r.b));
+        q3c_profile_entry& e = agg[r.name];
+        if (!e.launches) { std::memset(&e, 0, sizeof(e)); std::snprintf(e.kernel, sizeof(e.kernel), "%s", r.name); }
+        e.launches += 1; e.ms += ms; e.flops += r.flops; e.bytes += r.bytes;
+    }
+    int n = 0;
+    for (auto& kv : agg) { if (n < cap) out[n++] = kv.second; }
+    *count = n;
     return 0;
 }
 

@@ -241,6 +241,19 @@ class Decoder:
         return [host[s:s + n].copy() for s, n in zip(starts, lengths)], self.cfg.sample_rate
 
     # ------------------------------------------------------------------------------------------------
+    def profile(self, on: bool) -> None:
+        """Bracket every kernel launch of the following forwards with HIP events (see q3c_profile_enable)."""
+        self._check(self._lib.q3c_profile_enable(self._ctx, 1 if on else 0))
+
+    def profile_read(self) -> List[dict]:
+        """Per-kernel launches, summed milliseconds and algorithmic flops / bytes since profile(True)."""
+        cap = 64
+        arr = (_lib.Q3cProfileEntry * cap)()
+        n = C.c_int32()
+        self._check(self._lib.q3c_profile_read(self._ctx, arr, cap, C.byref(n)))
+        return [dict(kernel=arr[i].kernel.decode(), launches=int(arr[i].launches), ms=float(arr[i].ms),
+                     flops=float(arr[i].flops), bytes=float(arr[i].bytes)) for i in range(n.value)]
+
     def set_tap(self, stage: int, elements: int) -> torch.Tensor:
         """Debug/parity aid: capture a stage's output of the following forwards as fp32 (see include/q3c.h)."""
         buf = torch.zeros(elements, dtype=torch.float32, device=self.device)

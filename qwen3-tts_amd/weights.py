@@ -91,7 +91,9 @@ def param_specs(cfg: DecoderConfig) -> List[Tuple[str, Tuple[int, ...], str, flo
         p = f"decoder.{i + 1}.block."
         s.append((p + "0.alpha", (cin,), _SNAKE, 1.0))
         s.append((p + "0.beta", (cin,), _SNAKE, 1.0))
-        s.append((p + "1.conv.weight", (cin, cout, 2 * r), _W, cin * 2))    # 2 taps reach each output
+        # 2 taps reach each output; gain 2/3 undoes the ~1.5x growth of the three residual units that follow,
+        # so activations stay O(1) through the four blocks instead of growing 5x
+        s.append((p + "1.conv.weight", (cin, cout, 2 * r), _W, cin * 2 * 2.25))
         s.append((p + "1.conv.bias", (cout,), _B, 1.0))
         for j, _d in enumerate(cfg.dilations):
             q = p + f"{j + 2}."
@@ -107,7 +109,7 @@ def param_specs(cfg: DecoderConfig) -> List[Tuple[str, Tuple[int, ...], str, flo
     cl = cfg.block_channels[-1][1]
     s.append((f"decoder.{nb + 1}.alpha", (cl,), _SNAKE, 1.0))
     s.append((f"decoder.{nb + 1}.beta", (cl,), _SNAKE, 1.0))
-    s.append((f"decoder.{nb + 2}.conv.weight", (1, cl, 7), _W, cl * 7 * 400.0))  # keeps most samples inside the clamp
+    s.append((f"decoder.{nb + 2}.conv.weight", (1, cl, 7), _W, cl * 7 * 36.0))   # keeps most samples inside the clamp
     s.append((f"decoder.{nb + 2}.conv.bias", (1,), _B, 1.0))
     return s
 
