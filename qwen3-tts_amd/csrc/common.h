@@ -17,6 +17,7 @@ enum Q3Act : int {
     Q3_ACT_GELU = 1,    // exact erf GELU
     Q3_ACT_SNAKE = 2,   // x + invb * sin(a x)^2 with per-output-channel (a, invb)
     Q3_ACT_SWIGLU = 3,  // adjacent 32-column tiles hold (gate, up); out = silu(gate) * up, N_out = N / 2
+    Q3_ACT_CLAMP = 4,   // clamp(x, -1, 1)
 };
 
 // out[b, m, n] = post( R[b, m, n] + scale[n] * act( bias[n] + sum_tap sum_k pro(X[b, m + off0 + tap*off_step, k]) * W[tap][n][k] ) )
@@ -73,8 +74,25 @@ template <> __device__ __forceinline__ bf16 q3_from_f32<bf16>(float v) { return 
 
 // Accurate sine for the fp32 path (parity bar 1e-3 after ~40 layers); the hardware v_sin for the bf16 path,
 // whose storage rounding (2^-9 relative) is far coarser than v_sin's error.
+// fp32 sine, branch-free: x = k*pi + r by a three-term Cody-Waite reduction, odd degree-11 polynomial on
+// |r| <= pi/2, sign from the parity of k.  Absolute error <= 2.2e-7 for |x| <= 300 (the libm sinf inlined 16 times
+// per accumulator tile makes the kernel too large to unroll, which pushes the accumulators to scratch).
+__device__ __forceinline__ float q3_sin_f32(float x) {
+    const float k = rintf(x * 0.318309886183790671538f);
+    float r = fmaf(k, -3.140625f, x);
+    r = fmaf(k, -9.67502593994140625e-4f, r);
+    r = fmaf(k, -1.509957990978376432e-7f, r);
+    const float r2 = r * r;
+    float p = -2.50521083854417188e-8f;
+    p = fmaf(p, r2, 2.75573192239858907e-6f);
+    p = fmaf(p, r2, -1.98412698412698413e-4f);
+    p = fmaf(p, r2, 8.33333333333333333e-3f);
+    p = fmaf(p, r2, -1.66666666666666667e-1f);
+    p = fmaf(r * r2, p, r);
+    return ((int)k & 1) ? -p : p;
+}
 template <typename T> __device__ __forceinline__ float q3_sin(float x);
-template <> __device__ __forceinline__ float q3_sin<float>(float x) { return sinf(x); }
+template <> __device__ __forceinline__ float q3_sin<float>(float x) { return q3_sin_f32(x); }
 template <> __device__ __forceinline__ float q3_sin<bf16>(float x) { return __sinf(x); }
 
 template <typename T> __device__ __forceinline__ float q3_snake(float x, float a, float invb) {

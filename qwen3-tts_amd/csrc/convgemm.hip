@@ -228,59 +228,107 @@ __global__ void __launch_bounds__(256) convgemm_kernel(const ConvGemmArgs p) {
         tap = ntap; kc = nkc_;
     }
 
-    // ---- epilogue ----------------------------------------------------------------------------------
+    // ---- epilogue -----------------------------------------------------------------------------------
+    // The accumulator layout gives each lane ONE column of 16 rows.  Each wave passes its tile through a private
+    // fp32 LDS slab, 32 rows at a time, so that the global side is 16 contiguous bytes per lane: a row of the tile
+    // is stored (and its residual loaded) as whole 16-byte pieces by consecutive lanes.
     TO* __restrict__ Yb = (TO*)p.Y + (long long)b * p.y_batch_stride;
     const TO* __restrict__ Rb = p.R ? (const TO*)p.R + (long long)b * p.r_batch_stride : nullptr;
-    const int mbase = m0 + wm * 32 * WM + 4 * (lane >> 5);
+    constexpr int EPO = 16 / (int)sizeof(TO);            // output elements per 16-byte piece
+    constexpr int WCOLS = 32 * WN;
+    constexpr int SLD = WCOLS + 4;                        // slab row stride in floats (keeps rows 16-byte aligned)
+    float* slab = (float*)smem + wave * (32 * SLD);
+    const bool swiglu = p.act == Q3_ACT_SWIGLU;
+    const int wcols = swiglu ? WCOLS / 2 : WCOLS;         // output columns of this wave's tile
+    const int ncol0 = swiglu ? ((n0 >> 1) + wn * (WCOLS / 2)) : (n0 + wn * WCOLS);
+    const int n_out = swiglu ? p.N / 2 : p.N;
+    const bool has_post = p.post_a != nullptr;
+    const bool vec_ok = (p.ldy % EPO == 0) && (!Rb || p.ldr % EPO == 0) && (n_out % EPO == 0);
+    const int cprw = wcols / EPO;                         // 16-byte pieces per tile row
+    const int half = lane >> 5, l31 = lane & 31;
 
-    if (p.act == Q3_ACT_SWIGLU) {
-        if constexpr (WN % 2 == 0) {
-            const int n_out_total = p.N / 2;
 #pragma unroll
-            for (int j = 0; j < WN; j += 2) {
-                const int tile = (n0 >> 5) + wn * WN + j;          // even: gate tile, tile + 1: up tile
-                const int n = (tile >> 1) * 32 + (lane & 31);
-                if (n >= n_out_total) continue;
-                const float sc = p.scale ? p.scale[n] : 1.f;
+    for (int i = 0; i < WM; ++i) {
+        // phase 1: column-wise math, accumulators -> slab
+        if (swiglu) {
+            if constexpr (WN % 2 == 0) {
 #pragma unroll
-                for (int i = 0; i < WM; ++i)
+                for (int j = 0; j < WN; j += 2) {
+                    const int cl = (j >> 1) * 32 + l31;
+                    const int n = ncol0 + cl;
+                    const float sc = (p.scale && n < n_out) ? p.scale[n] : 1.f;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        int m = mbase + i * 32 + (r & 3) + 8 * (r >> 2);
-                        if (m >= p.M) continue;
-                        float v = q3_silu(acc[i][j][r]) * acc[i][j + 1][r] * sc;
-                        if (Rb) v += q3_to_f32(Rb[(long long)m * p.ldr + n]);
-                        Yb[(long long)m * p.ldy + n] = q3_from_f32<TO>(v);
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                        slab[row * SLD + cl] = q3_silu(acc[i][j][r]) * acc[i][j + 1][r] * sc;
                     }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const int cl = j * 32 + l31;
+                const int n = ncol0 + cl;
+                const bool nv = n < n_out;
+                const float bias = (p.bias && nv) ? p.bias[n] : 0.f;
+                const float sc = (p.scale && nv) ? p.scale[n] : 1.f;
+                float ea = 0.f, eib = 0.f;
+                if (p.act == Q3_ACT_SNAKE && nv) { ea = p.epi_a[n]; eib = p.epi_invb[n]; }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    float v = acc[i][j][r] + bias;
+                    if (p.act == Q3_ACT_GELU) v = q3_gelu(v);
+                    else if (p.act == Q3_ACT_SNAKE) v = q3_snake<TO>(v, ea, eib);
+                    else if (p.act == Q3_ACT_CLAMP) v = fminf(1.0f, fmaxf(-1.0f, v));
+                    slab[row * SLD + cl] = v * sc;
+                }
             }
         }
-        return;
-    }
-
+        __builtin_amdgcn_wave_barrier();
+        // phase 2: row-wise, 16 bytes per lane: + residual, snake of the consumer, store
+        const int mrow0 = m0 + wm * 32 * WM + i * 32;
+        for (int id = lane; id < 32 * cprw; id += 64) {
+            const int row = id / cprw, ch = id - row * cprw;
+            const int m = mrow0 + row, n = ncol0 + ch * EPO;
+            if (m >= p.M || n >= n_out) continue;
+            float v[EPO];
+            const float* sp = slab + row * SLD + ch * EPO;
 #pragma unroll
-    for (int j = 0; j < WN; ++j) {
-        const int n = n0 + wn * 32 * WN + j * 32 + (lane & 31);
-        if (n >= p.N) continue;
-        const float bias = p.bias ? p.bias[n] : 0.f;
-        const float sc = p.scale ? p.scale[n] : 1.f;
-        float ea = 0.f, eib = 0.f, qa = 0.f, qib = 0.f;
-        if (p.act == Q3_ACT_SNAKE) { ea = p.epi_a[n]; eib = p.epi_invb[n]; }
-        const bool has_post = p.post_a != nullptr;
-        if (has_post) { qa = p.post_a[n]; qib = p.post_invb[n]; }
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int m = mbase + i * 32 + (r & 3) + 8 * (r >> 2);
-                if (m >= p.M) continue;
-                float v = acc[i][j][r] + bias;
-                if (p.act == Q3_ACT_GELU) v = q3_gelu(v);
-                else if (p.act == Q3_ACT_SNAKE) v = q3_snake<TO>(v, ea, eib);
-                v *= sc;
-                if (Rb) v += q3_to_f32(Rb[(long long)m * p.ldr + n]);
-                if (has_post) v = q3_snake<TO>(v, qa, qib);
-                Yb[(long long)m * p.ldy + n] = q3_from_f32<TO>(v);
+            for (int e = 0; e < EPO; e += 4) {
+                const float4 t4 = *(const float4*)(sp + e);
+                v[e] = t4.x; v[e + 1] = t4.y; v[e + 2] = t4.z; v[e + 3] = t4.w;
             }
+            TO* yp = Yb + (long long)m * p.ldy + n;
+            if (vec_ok) {
+                if (Rb) {
+                    const uint4 raw = *(const uint4*)(Rb + (long long)m * p.ldr + n);
+                    const TO* rr = (const TO*)&raw;
+#pragma unroll
+                    for (int e = 0; e < EPO; ++e) v[e] += q3_to_f32(rr[e]);
+                }
+                if (has_post) {
+#pragma unroll
+                    for (int e = 0; e < EPO; ++e) v[e] = q3_snake<TO>(v[e], p.post_a[n + e], p.post_invb[n + e]);
+                }
+                uint4 outv;
+                TO* oo = (TO*)&outv;
+#pragma unroll
+                for (int e = 0; e < EPO; ++e) oo[e] = q3_from_f32<TO>(v[e]);
+                *(uint4*)yp = outv;
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPO; ++e) {
+                    if (n + e < n_out) {
+                        float x = v[e];
+                        if (Rb) x += q3_to_f32(Rb[(long long)m * p.ldr + n + e]);
+                        if (has_post) x = q3_snake<TO>(x, p.post_a[n + e], p.post_invb[n + e]);
+                        yp[e] = q3_from_f32<TO>(x);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -294,6 +342,8 @@ hipError_t launch_cfg(const ConvGemmArgs& a, hipStream_t s) {
     const int xps = (xi_total + a.taps - 1) / a.taps;
     if (xps > (BM * CPR + 255) / 256) return hipErrorInvalidValue;      // halo too large for the staged-slice scheme
     size_t lds = 2 * (size_t)HR * BKB + 2 * (size_t)BN * BKB;
+    const size_t lds_epilogue = (size_t)4 * 32 * (32 * WN + 4) * sizeof(float);      // four wave-private slabs
+    if (lds_epilogue > lds) lds = lds_epilogue;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     auto kern = convgemm_kernel<TA, TO, WAVES_M, WAVES_N, WM, WN, BKB>;
     if (lds > 48 * 1024) {
@@ -307,9 +357,11 @@ hipError_t launch_cfg(const ConvGemmArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// tile shape selection: 0 = 256x96 tile / 64-byte K rows, 1 = 128x128 / 128-byte, 2 = 128x128 / 64-byte
+// tile shape selection: 0 = 256x96 tile / 64-byte K rows, 1 = 128x128 / 128-byte, 2 = 128x128 / 64-byte,
+// 3 = 256x32 / 64-byte (outputs of at most 32 channels: the final 1-channel convolution)
 int pick_shape(const ConvGemmArgs& a, size_t elem) {
     const bool wide_k = ((size_t)a.K * elem) % 128 == 0;
+    if (a.N <= 32 && a.act != Q3_ACT_SWIGLU) return 3;
     const bool use_96 = (a.act != Q3_ACT_SWIGLU) && (a.N % 128 != 0) && (a.N % 96 == 0) && a.N < 512;
     return use_96 ? 0 : (wide_k ? 1 : 2);
 }
@@ -319,18 +371,20 @@ hipError_t launch_typed(const ConvGemmArgs& a, hipStream_t s) {
     switch (pick_shape(a, sizeof(TA))) {
         case 0: return launch_cfg<TA, TO, 4, 1, 2, 3, 64>(a, s);
         case 1: return launch_cfg<TA, TO, 2, 2, 2, 2, 128>(a, s);
-        default: return launch_cfg<TA, TO, 2, 2, 2, 2, 64>(a, s);
+        case 2: return launch_cfg<TA, TO, 2, 2, 2, 2, 64>(a, s);
+        default: return launch_cfg<TA, TO, 4, 1, 2, 1, 64>(a, s);
     }
 }
 
 }  // namespace
 
 const char* q3_convgemm_variant(const ConvGemmArgs& a, int in_dtype, int out_dtype) {
-    static const char* names[3][3] = {
-        {"convgemm<f32,f32,256x96,k64B>", "convgemm<f32,f32,128x128,k128B>", "convgemm<f32,f32,128x128,k64B>"},
-        {"convgemm<bf16,bf16,256x96,k64B>", "convgemm<bf16,bf16,128x128,k128B>", "convgemm<bf16,bf16,128x128,k64B>"},
-        {"convgemm<f32,bf16,256x96,k64B>", "convgemm<f32,bf16,128x128,k128B>", "convgemm<f32,bf16,128x128,k64B>"}};
-    const int t = (in_dtype == Q3_F32 && out_dtype == Q3_F32) ? 0 : (in_dtype == Q3_BF16 ? 1 : 2);
+    static const char* names[4][4] = {
+        {"convgemm<f32,f32,256x96,k64B>", "convgemm<f32,f32,128x128,k128B>", "convgemm<f32,f32,128x128,k64B>", "convgemm<f32,f32,256x32,k64B>"},
+        {"convgemm<bf16,bf16,256x96,k64B>", "convgemm<bf16,bf16,128x128,k128B>", "convgemm<bf16,bf16,128x128,k64B>", "convgemm<bf16,bf16,256x32,k64B>"},
+        {"convgemm<f32,bf16,256x96,k64B>", "convgemm<f32,bf16,128x128,k128B>", "convgemm<f32,bf16,128x128,k64B>", "convgemm<f32,bf16,256x32,k64B>"},
+        {"convgemm<bf16,f32,256x96,k64B>", "convgemm<bf16,f32,128x128,k128B>", "convgemm<bf16,f32,128x128,k64B>", "convgemm<bf16,f32,256x32,k64B>"}};
+    const int t = (in_dtype == Q3_F32 && out_dtype == Q3_F32) ? 0 : (in_dtype == Q3_BF16 ? (out_dtype == Q3_BF16 ? 1 : 3) : 2);
     return names[t][pick_shape(a, in_dtype == Q3_BF16 ? 2 : 4)];
 }
 
@@ -343,5 +397,6 @@ hipError_t q3_launch_convgemm(const ConvGemmArgs& a, int in_dtype, int out_dtype
     if (in_dtype == Q3_F32 && out_dtype == Q3_F32) return launch_typed<float, float>(a, s);
     if (in_dtype == Q3_BF16 && out_dtype == Q3_BF16) return launch_typed<bf16, bf16>(a, s);
     if (in_dtype == Q3_F32 && out_dtype == Q3_BF16) return launch_typed<float, bf16>(a, s);
+    if (in_dtype == Q3_BF16 && out_dtype == Q3_F32) return launch_typed<bf16, float>(a, s);
     return hipErrorInvalidValue;
 }

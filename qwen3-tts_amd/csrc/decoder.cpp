@@ -59,7 +59,7 @@ struct q3c_ctx {
     GemmW conv_in;
     std::vector<Block> blocks;
     Snake final_snake;
-    float* out_w = nullptr; float out_b = 0.f; int out_k = 0;
+    GemmW conv_out;
 
     int* err_flag = nullptr;
     std::map<int, std::pair<float*, size_t>> taps;
@@ -539,16 +539,7 @@ int q3c_finalize(q3c_ctx* c) {
     }
     const int nb = k.num_upsample_rates;
     TRY(pack_snake(c, "decoder." + std::to_string(nb + 1) + ".", ch, &c->final_snake));
-    {
-        GETW(w, "decoder." + std::to_string(nb + 2) + ".conv.weight", 1, ch, 7);
-        GETW(b, "decoder." + std::to_string(nb + 2) + ".conv.bias", 1);
-        std::vector<float> wt((size_t)7 * ch);
-        for (int cc = 0; cc < ch; ++cc)
-            for (int j = 0; j < 7; ++j) wt[(size_t)j * ch + cc] = w->data[(size_t)cc * 7 + j];
-        TRY(upload_f32(c, wt, &c->out_w));
-        c->out_b = b->data[0];
-        c->out_k = 7;
-    }
+    TRY(pack_conv(c, "decoder." + std::to_string(nb + 2) + ".conv", 1, ch, 7, 1, dt, &c->conv_out));
     c->staged.clear();
     c->finalized = true;
     return 0;
@@ -705,7 +696,10 @@ int q3c_forward(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, float* w
         std::swap(cur, other);
         TRY(tap_out(c, Q3C_STAGE_BLOCK0 + (int)i, cur, (size_t)B * L * ch, s));
     }
-    LAUNCH_B(c, s, "conv_out_clamp", (size_t)B * L * (ch * es + 4), q3_launch_conv_out(cur, c->out_w, c->out_b, wav, B, L, ch, c->out_k, dt, s));
+    {   // final conv to one channel, clamp fused, fp32 samples out
+        GemmOpts g; g.act = Q3_ACT_CLAMP;
+        TRY(gemm(c, c->conv_out, cur, B, L, wav, L, Q3_F32, g, s));
+    }
     return 0;
 }
 
