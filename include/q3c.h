@@ -118,7 +118,7 @@ typedef struct q3c_profile_entry {
     int64_t launches;
     double ms, flops, bytes;
 } q3c_profile_entry;
-int q3c_profile_enable(q3c_ctx* ctx, int32_t on);
+int q3c_profile_enable(q3c_ctx* ctx, int32_t on);   /* 0 off, 1 per kernel, 2 per (kernel, layer shape) */
 int q3c_profile_read(q3c_ctx* ctx, q3c_profile_entry* out, int32_t capacity, int32_t* count);
 
 /* -- single operators (host weights in the PyTorch layout are repacked and uploaded per call: meant for

@@ -1,23 +1,36 @@
 // Multi-tap row-shifted GEMM on the gfx950 matrix cores: the one dense-contraction kernel of the decode.
 //
-//   out[b, m, n] = post( R[b,m,n] + scale[n] * act( bias[n] + sum_tap sum_k pro(X[b, m + off0 + tap*off_step, k]) * W[tap][n][k] ) )
+//   h[b, m, n]   = act( bias[n] + sum_tap sum_k pro(X[b, m + off0 + tap*off_step, k]) * W[tap][n][k] ) * scale[n]
+//   FUSE2 only:    h <- bias2[n] + sum_j h[b, m, j] * W2[n][j]                (a second, 1x1 contraction in the same launch)
+//   y            = R[b, m, n] + h
+//   Y <- y (or post(y) when Y2 is null);   Y2 <- post(y)                      (post = SnakeBeta of the consumer)
 //
 // With channels-last activations every layer of the decoder is this form:
 //   causal Conv1d(k, dilation d)      taps = k, off0 = -(k-1)d, off_step = d
 //   ConvTranspose1d(k = 2s, stride s) taps = 2, off0 = 0, off_step = 1, N = s*Cout  (row q of [L-1, s*Cout] IS rows q*s .. q*s+s-1 of [.., Cout])
 //   ConvTranspose1d(k = s,  stride s) taps = 1, N = s*Cout
 //   Linear                            taps = 1
-// A block owns a BM x BN output tile.  Per K-chunk the (BM + halo) input rows are staged ONCE in LDS and
-// every tap reads them at a row offset, so the im2col matrix never exists.  Weight tiles are staged per
-// (K-chunk, tap) step; both operands are prefetched into registers one step ahead and land in the other
-// LDS buffer after the step's MFMAs (one barrier per step).  LDS rows are BKB bytes with a 16-byte-chunk
-// XOR swizzle so that the 16-lane groups of ds_read_b128 touch 16 distinct 16-byte slots.
+//   residual unit                     FUSE2: snake -> conv k7 -> snake -> conv k1 -> + x in ONE launch
 //
-// Element types: bf16 operands -> v_mfma_f32_32x32x16_bf16; fp32 operands -> v_mfma_f32_32x32x2_f32
-// (bit-exact fp32 FMA chains, used by the parity path).  Accumulation is fp32 in both.
+// A block owns a BM x BN output tile.  Per K-chunk the (BM + halo) input rows are staged ONCE in LDS and every tap
+// reads them at a row offset, so the im2col matrix never exists.  Weight tiles are staged per (K-chunk, tap) step.
+// Staging is double-buffered one step ahead.  Weights - and inputs that need no transform - go global -> LDS
+// directly (LDS-DMA: `global_load_lds` / `buffer_load ... lds`, 16 bytes per lane), with rows outside the sequence
+// zero-filled by the buffer descriptor's range check; inputs with a SnakeBeta prologue pass through registers.
+// LDS rows are BKB bytes; 16-byte chunk c of row r sits at slot c ^ f(r), so the 16-lane groups of ds_read_b128 touch
+// 16 distinct slots; with LDS-DMA the destination is lane-linear and the XOR is applied to the SOURCE address.
+//
+// Element types: bf16 operands -> v_mfma_f32_32x32x16_bf16; fp32 operands -> v_mfma_f32_32x32x2_f32 (bit-exact fp32
+// FMA chains, used by the parity path).  Accumulation is fp32 in both.
 #include "common.h"
 
+#include <algorithm>
+#include <cstdio>
+
 namespace {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void global_cvoid;
 
 template <int CPR> __device__ __forceinline__ int swz(int row, int c) {
     if constexpr (CPR == 8) return c ^ ((row >> 1) & 7);
@@ -57,7 +70,9 @@ template <> __device__ __forceinline__ uint4 snake_piece<bf16>(uint4 v, const fl
     return __builtin_bit_cast(uint4, h);
 }
 
-template <typename TA, typename TO, int WAVES_M, int WAVES_N, int WM, int WN, int BKB>
+__host__ __device__ constexpr size_t round_kb(size_t v) { return (v + 1023) / 1024 * 1024; }
+
+template <typename TA, typename TO, int WAVES_M, int WAVES_N, int WM, int WN, int BKB, bool FUSE2>
 __global__ void __launch_bounds__(256) convgemm_kernel(const ConvGemmArgs p) {
     constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
     constexpr int CPR = BKB / 16;                    // 16-byte chunks per LDS row
@@ -65,14 +80,18 @@ __global__ void __launch_bounds__(256) convgemm_kernel(const ConvGemmArgs p) {
     constexpr int BK = CPR * EPC;                    // K elements per chunk row
     constexpr int KG = BKB / 32;                     // fragment groups per step
     constexpr int NTHR = 256;
-    constexpr int WITER = (BN * CPR + NTHR - 1) / NTHR;
+    constexpr int WPIECES = BN * CPR;
+    constexpr int WITER = (WPIECES + NTHR - 1) / NTHR;
     constexpr int MAX_XPS = (BM * CPR + NTHR - 1) / NTHR;
+    constexpr size_t WBUF = round_kb((size_t)BN * BKB);
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
     static_assert(NTHR % CPR == 0, "column chunk of a thread is fixed");
+    static_assert(!FUSE2 || WAVES_N == 1, "the fused second contraction needs whole rows per wave");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     // 1-D tile index with the N tiles fastest: blocks that share an input tile are dispatched together
     const int n_tiles = (p.N + BN - 1) / BN;
@@ -85,16 +104,28 @@ __global__ void __launch_bounds__(256) convgemm_kernel(const ConvGemmArgs p) {
     const int xpieces = HR * CPR;
     const int xi_total = (xpieces + NTHR - 1) / NTHR;
     const int xps = (xi_total + p.taps - 1) / p.taps;   // pieces per thread per step (<= MAX_XPS, host-checked)
+    const size_t XBUF = round_kb((size_t)HR * BKB);
+    const size_t region0 = FUSE2 ? (2 * XBUF > (size_t)BM * (p.N * sizeof(TA) + 16) ? 2 * XBUF : (size_t)BM * (p.N * sizeof(TA) + 16))
+                                 : 2 * XBUF;
 
     unsigned char* Xs0 = smem;
-    unsigned char* Ws0 = smem + 2 * (size_t)HR * BKB;
+    unsigned char* Ws0 = smem + round_kb(region0);
 
     const TA* __restrict__ Xb = (const TA*)p.X + (long long)b * p.x_batch_stride;
-    const TA* __restrict__ Wg = (const TA*)p.W;
     const int nkc = (p.K + BK - 1) / BK;
     const int nsteps = nkc * p.taps;
     const int my_c = tid % CPR;                      // column chunk of every piece this thread stages
     const bool has_pro = p.pro_a != nullptr;
+    const bool w_dma = (p.K % BK) == 0;              // whole chunks only: LDS-DMA cannot zero-fill a K tail
+    const bool x_dma = w_dma && !has_pro;
+
+    // buffer descriptor over the rows of X this tile may touch; anything else reads as zero
+    const int g0 = m0 + p.off0;
+    const int r_lo = g0 > 0 ? g0 : 0;
+    const int r_hi = (g0 + HR) < p.L_in ? (g0 + HR) : p.L_in;
+    const long long xrec = (long long)(r_hi > r_lo ? r_hi - r_lo : 0) * p.ldx * (int)sizeof(TA);
+    const __amdgpu_buffer_rsrc_t xrsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(Xb + (long long)r_lo * p.ldx), 0, (int)xrec, 0x00020000);
 
     float pa[EPC], pib[EPC];
     auto load_pro = [&](int kc) {
@@ -108,9 +139,10 @@ __global__ void __launch_bounds__(256) convgemm_kernel(const ConvGemmArgs p) {
             }
         }
     };
+    // ---- input tile, register path ----
     auto x_load = [&](int id, int kc) -> uint4 {
         int row = id / CPR;
-        int grow = m0 + p.off0 + row;
+        int grow = g0 + row;
         int kel = kc * BK + my_c * EPC;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (id < xpieces && grow >= 0 && grow < p.L_in && kel < p.K)
@@ -124,19 +156,44 @@ __global__ void __launch_bounds__(256) convgemm_kernel(const ConvGemmArgs p) {
             *(uint4*)(xs + (size_t)row * BKB + swz<CPR>(row, my_c) * 16) = v;
         }
     };
-    auto w_load = [&](int id, int kc, int tap) -> uint4 {
+    // ---- input tile, LDS-DMA path: iteration `it` of wave w writes the 1 KiB at (it*4 + w) KiB of the buffer ----
+    auto x_dma_issue = [&](unsigned char* xs, int it, int kc) {
+        if ((it * 4 + wave) * 64 >= xpieces) return;             // wave-uniform: this wave's 1 KiB lies past the tile
+        const int id = tid + it * NTHR;
+        const int row = id / CPR;
+        const int c = swz<CPR>(row, my_c);                       // slot my_c of this row must receive chunk c
+        long long off = ((long long)(g0 + row - r_lo) * p.ldx + kc * BK + c * EPC) * (int)sizeof(TA);
+        unsigned voff = (id < xpieces && off >= 0 && off < xrec) ? (unsigned)off : 0x7fffff00u;   // out of range -> zeros
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)(xs + (size_t)(it * 4 + wave) * 1024), 16, voff, 0, 0, 0);
+    };
+    // ---- weight tile ----
+    auto w_load = [&](const TA* Wg, int ldw, int id, int kc, int tap) -> uint4 {
         int row = id / CPR, c = id % CPR;
         int n = n0 + row;
         int kel = kc * BK + c * EPC;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (id < BN * CPR && n < p.N && kel < p.K)
-            v = *(const uint4*)(Wg + ((long long)tap * p.N + n) * p.K + kel);
+        if (id < WPIECES && n < p.N && kel < ldw)
+            v = *(const uint4*)(Wg + ((long long)tap * p.N + n) * ldw + kel);
         return v;
     };
     auto w_store = [&](unsigned char* ws, int id, uint4 v) {
-        if (id < BN * CPR) {
+        if (id < WPIECES) {
             int row = id / CPR, c = id % CPR;
             *(uint4*)(ws + (size_t)row * BKB + swz<CPR>(row, c) * 16) = v;
+        }
+    };
+    auto w_dma_issue = [&](unsigned char* ws, const TA* Wg, int ldw, int kc, int tap) {
+#pragma unroll
+        for (int q = 0; q < WITER; ++q) {
+            if ((q * 4 + wave) * 64 < WPIECES) {                 // wave-uniform
+                const int id = (q * 4 + wave) * 64 + lane;
+                const int row = id / CPR, cs = id % CPR;
+                const int c = swz<CPR>(row, cs);
+                int n = n0 + row;
+                n = n < p.N ? n : p.N - 1;                       // columns past N are never stored: any finite row will do
+                const TA* src = Wg + ((long long)tap * p.N + n) * ldw + kc * BK + c * EPC;
+                __builtin_amdgcn_global_load_lds((global_cvoid*)src, (lds_void*)(ws + (size_t)(q * 4 + wave) * 1024), 16, 0, 0);
+            }
         }
     };
 
@@ -148,18 +205,29 @@ __global__ void __launch_bounds__(256) convgemm_kernel(const ConvGemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    const TA* __restrict__ Wg = (const TA*)p.W;
+
     // ---- prologue: whole X tile of chunk 0, W tile of step 0 -------------------------------------
-    load_pro(0);
-    for (int it = 0; it < xi_total; ++it) {
-        int id = tid + it * NTHR;
-        x_store(Xs0, id, x_load(id, 0));
+    if (x_dma) {
+        for (int it = 0; it < xi_total; ++it) x_dma_issue(Xs0, it, 0);
+    } else {
+        load_pro(0);
+        for (int it = 0; it < xi_total; ++it) {
+            int id = tid + it * NTHR;
+            x_store(Xs0, id, x_load(id, 0));
+        }
+        load_pro(1);
     }
-    load_pro(1);
+    if (w_dma) {
+        w_dma_issue(Ws0, Wg, p.K, 0, 0);
+    } else {
 #pragma unroll
-    for (int it = 0; it < WITER; ++it) {
-        int id = tid + it * NTHR;
-        w_store(Ws0, id, w_load(id, 0, 0));
+        for (int it = 0; it < WITER; ++it) {
+            int id = tid + it * NTHR;
+            w_store(Ws0, id, w_load(Wg, p.K, id, 0, 0));
+        }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     int kc = 0, tap = 0;
@@ -168,25 +236,39 @@ __global__ void __launch_bounds__(256) convgemm_kernel(const ConvGemmArgs p) {
         if (ntap == p.taps) { ntap = 0; nkc_ = kc + 1; }
         const bool has_next = (step + 1) < nsteps;
         const bool x_next = (kc + 1) < nkc;
+        unsigned char* wsn = Ws0 + (size_t)((step + 1) & 1) * WBUF;
+        unsigned char* xsn = Xs0 + (size_t)((kc + 1) & 1) * XBUF;
 
-        // issue next step's global loads
+        // issue next step's loads: straight into the other LDS buffers, or into registers
         uint4 wreg[WITER];
         uint4 xreg[MAX_XPS];
         if (has_next) {
+            if (w_dma) {
+                w_dma_issue(wsn, Wg, p.K, nkc_, ntap);
+            } else {
 #pragma unroll
-            for (int it = 0; it < WITER; ++it) wreg[it] = w_load(tid + it * NTHR, nkc_, ntap);
+                for (int it = 0; it < WITER; ++it) wreg[it] = w_load(Wg, p.K, tid + it * NTHR, nkc_, ntap);
+            }
         }
         if (x_next) {
+            if (x_dma) {
 #pragma unroll
-            for (int i = 0; i < MAX_XPS; ++i) {
-                int it = tap * xps + i;
-                xreg[i] = (i < xps && it < xi_total) ? x_load(tid + it * NTHR, kc + 1) : make_uint4(0, 0, 0, 0);
+                for (int i = 0; i < MAX_XPS; ++i) {
+                    int it = tap * xps + i;
+                    if (i < xps && it < xi_total) x_dma_issue(xsn, it, kc + 1);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < MAX_XPS; ++i) {
+                    int it = tap * xps + i;
+                    xreg[i] = (i < xps && it < xi_total) ? x_load(tid + it * NTHR, kc + 1) : make_uint4(0, 0, 0, 0);
+                }
             }
         }
 
         // MFMAs of this step
-        const unsigned char* xs = Xs0 + (size_t)(kc & 1) * HR * BKB;
-        const unsigned char* ws = Ws0 + (size_t)(step & 1) * BN * BKB;
+        const unsigned char* xs = Xs0 + (size_t)(kc & 1) * XBUF;
+        const unsigned char* ws = Ws0 + (size_t)(step & 1) * WBUF;
         const int arow0 = wm * 32 * WM + (lane & 31) + tap * p.off_step;
         const int brow0 = wn * 32 * WN + (lane & 31);
 #pragma unroll
@@ -209,143 +291,240 @@ __global__ void __launch_bounds__(256) convgemm_kernel(const ConvGemmArgs p) {
                 for (int j = 0; j < WN; ++j) Mma<TA>::run(af[i], bfr[j], acc[i][j]);
         }
 
-        // land the prefetched tiles in the other buffers
-        if (has_next) {
-            unsigned char* wsn = Ws0 + (size_t)((step + 1) & 1) * BN * BKB;
+        // land the register-staged tiles in the other buffers
+        if (has_next && !w_dma) {
 #pragma unroll
             for (int it = 0; it < WITER; ++it) w_store(wsn, tid + it * NTHR, wreg[it]);
         }
-        if (x_next) {
-            unsigned char* xsn = Xs0 + (size_t)((kc + 1) & 1) * HR * BKB;
+        if (x_next && !x_dma) {
 #pragma unroll
             for (int i = 0; i < MAX_XPS; ++i) {
                 int it = tap * xps + i;
                 if (i < xps && it < xi_total) x_store(xsn, tid + it * NTHR, xreg[i]);
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (ntap == 0) load_pro(nkc_ + 1);   // parameters for the tile staged during the next chunk's steps
+        if (ntap == 0 && !x_dma) load_pro(nkc_ + 1);   // parameters for the tile staged during the next chunk's steps
         tap = ntap; kc = nkc_;
     }
 
-    // ---- epilogue -----------------------------------------------------------------------------------
-    // The accumulator layout gives each lane ONE column of 16 rows.  Each wave passes its tile through a private
-    // fp32 LDS slab, 32 rows at a time, so that the global side is 16 contiguous bytes per lane: a row of the tile
-    // is stored (and its residual loaded) as whole 16-byte pieces by consecutive lanes.
-    TO* __restrict__ Yb = (TO*)p.Y + (long long)b * p.y_batch_stride;
-    const TO* __restrict__ Rb = p.R ? (const TO*)p.R + (long long)b * p.r_batch_stride : nullptr;
-    constexpr int EPO = 16 / (int)sizeof(TO);            // output elements per 16-byte piece
-    constexpr int WCOLS = 32 * WN;
-    constexpr int SLD = WCOLS + 4;                        // slab row stride in floats (keeps rows 16-byte aligned)
-    float* slab = (float*)smem + wave * (32 * SLD);
-    const bool swiglu = p.act == Q3_ACT_SWIGLU;
-    const int wcols = swiglu ? WCOLS / 2 : WCOLS;         // output columns of this wave's tile
-    const int ncol0 = swiglu ? ((n0 >> 1) + wn * (WCOLS / 2)) : (n0 + wn * WCOLS);
-    const int n_out = swiglu ? p.N / 2 : p.N;
-    const bool has_post = p.post_a != nullptr;
-    const bool vec_ok = (p.ldy % EPO == 0) && (!Rb || p.ldr % EPO == 0) && (n_out % EPO == 0);
-    const int cprw = wcols / EPO;                         // 16-byte pieces per tile row
     const int half = lane >> 5, l31 = lane & 31;
 
+    // ---- fused second contraction (k = 1): h = snake(acc + bias) -> LDS -> acc = h . W2^T -------------------------
+    if constexpr (FUSE2) {
+        const int HLD = p.N * (int)sizeof(TA) + 16;                 // padded row stride of the h tile
+        unsigned char* Hs = smem;                                   // overlays the (now idle) input buffers
+        const TA* __restrict__ W2 = (const TA*)p.W2;
+        const bool w2_dma = (p.N % BK) == 0;
+        // first W2 tile in flight while h is produced
+        if (w2_dma) w_dma_issue(Ws0, W2, p.N, 0, 0);
+        else {
 #pragma unroll
-    for (int i = 0; i < WM; ++i) {
-        // phase 1: column-wise math, accumulators -> slab
-        if (swiglu) {
-            if constexpr (WN % 2 == 0) {
+            for (int it = 0; it < WITER; ++it) w_store(Ws0, tid + it * NTHR, w_load(W2, p.N, tid + it * NTHR, 0, 0));
+        }
 #pragma unroll
-                for (int j = 0; j < WN; j += 2) {
-                    const int cl = (j >> 1) * 32 + l31;
-                    const int n = ncol0 + cl;
-                    const float sc = (p.scale && n < n_out) ? p.scale[n] : 1.f;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                        slab[row * SLD + cl] = q3_silu(acc[i][j][r]) * acc[i][j + 1][r] * sc;
-                    }
-                }
-            }
-        } else {
+        for (int i = 0; i < WM; ++i)
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
-                const int cl = j * 32 + l31;
-                const int n = ncol0 + cl;
-                const bool nv = n < n_out;
+                const int n = j * 32 + l31;
+                const bool nv = n < p.N;
                 const float bias = (p.bias && nv) ? p.bias[n] : 0.f;
-                const float sc = (p.scale && nv) ? p.scale[n] : 1.f;
                 float ea = 0.f, eib = 0.f;
                 if (p.act == Q3_ACT_SNAKE && nv) { ea = p.epi_a[n]; eib = p.epi_invb[n]; }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int row = wm * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                     float v = acc[i][j][r] + bias;
-                    if (p.act == Q3_ACT_GELU) v = q3_gelu(v);
-                    else if (p.act == Q3_ACT_SNAKE) v = q3_snake<TO>(v, ea, eib);
-                    else if (p.act == Q3_ACT_CLAMP) v = fminf(1.0f, fmaxf(-1.0f, v));
-                    slab[row * SLD + cl] = v * sc;
+                    if (p.act == Q3_ACT_SNAKE) v = q3_snake<TA>(v, ea, eib);
+                    if (nv) *(TA*)(Hs + (size_t)row * HLD + n * sizeof(TA)) = q3_from_f32<TA>(v);
+                    acc[i][j][r] = 0.f;
                 }
             }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int nkc2 = (p.N + BK - 1) / BK;
+        for (int s2 = 0; s2 < nkc2; ++s2) {
+            const bool has_next = (s2 + 1) < nkc2;
+            unsigned char* wsn = Ws0 + (size_t)((s2 + 1) & 1) * WBUF;
+            uint4 wreg[WITER];
+            if (has_next) {
+                if (w2_dma) w_dma_issue(wsn, W2, p.N, s2 + 1, 0);
+                else {
+#pragma unroll
+                    for (int it = 0; it < WITER; ++it) wreg[it] = w_load(W2, p.N, tid + it * NTHR, s2 + 1, 0);
+                }
+            }
+            const unsigned char* ws = Ws0 + (size_t)(s2 & 1) * WBUF;
+            const int arow0 = wm * 32 * WM + l31;
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg) {
+                const int c = kg * 2 + half;
+                const int kbyte = s2 * BKB + c * 16;
+                uint4 af[WM], bfr[WN];
+#pragma unroll
+                for (int i = 0; i < WM; ++i) {
+                    // columns past N (a K tail of the last chunk) multiply zero-filled weight columns; read them as zero too
+                    af[i] = (kbyte < p.N * (int)sizeof(TA)) ? *(const uint4*)(Hs + (size_t)(arow0 + i * 32) * HLD + kbyte)
+                                                            : make_uint4(0, 0, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    int row = j * 32 + l31;
+                    bfr[j] = *(const uint4*)(ws + (size_t)row * BKB + swz<CPR>(row, c) * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) Mma<TA>::run(af[i], bfr[j], acc[i][j]);
+            }
+            if (has_next && !w2_dma) {
+#pragma unroll
+                for (int it = 0; it < WITER; ++it) w_store(wsn, tid + it * NTHR, wreg[it]);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
         }
-        __builtin_amdgcn_wave_barrier();
-        // phase 2: row-wise, 16 bytes per lane: + residual, snake of the consumer, store
-        const int mrow0 = m0 + wm * 32 * WM + i * 32;
-        for (int id = lane; id < 32 * cprw; id += 64) {
-            const int row = id / cprw, ch = id - row * cprw;
-            const int m = mrow0 + row, n = ncol0 + ch * EPO;
-            if (m >= p.M || n >= n_out) continue;
-            float v[EPO];
-            const float* sp = slab + row * SLD + ch * EPO;
+    }
+
+    // ---- epilogue -----------------------------------------------------------------------------------
+    // The accumulator layout gives each lane ONE column of 16 rows.  Each wave passes its tile through a private
+    // fp32 LDS slab, 32 rows x <= 96 columns at a time, so that the global side is 16 contiguous bytes per lane:
+    // a row of the tile is stored (and its residual loaded) as whole 16-byte pieces by consecutive lanes.
+    TO* __restrict__ Yb = (TO*)p.Y + (long long)b * p.y_batch_stride;
+    TO* __restrict__ Y2b = p.Y2 ? (TO*)p.Y2 + (long long)b * p.y_batch_stride : nullptr;
+    const TO* __restrict__ Rb = p.R ? (const TO*)p.R + (long long)b * p.r_batch_stride : nullptr;
+    constexpr int EPO = 16 / (int)sizeof(TO);            // output elements per 16-byte piece
+    constexpr int JG = WN < 3 ? WN : 3;                   // column tiles per slab pass
+    constexpr int SCOLS = 32 * JG;
+    constexpr int SLD = SCOLS + 4;                        // slab row stride in floats (keeps rows 16-byte aligned)
+    static_assert(WN % JG == 0, "slab passes must tile the wave's columns");
+    float* slab = (float*)smem + wave * (32 * SLD);
+    const bool swiglu = p.act == Q3_ACT_SWIGLU;
+    const int n_out = swiglu ? p.N / 2 : p.N;
+    const bool has_post = p.post_a != nullptr;
+    const bool vec_ok = (p.ldy % EPO == 0) && (!Rb || p.ldr % EPO == 0) && (n_out % EPO == 0);
+    const int first_act = FUSE2 ? Q3_ACT_NONE : p.act;    // FUSE2 consumed the activation before its second contraction
+    const float* obias = FUSE2 ? p.bias2 : p.bias;
+
 #pragma unroll
-            for (int e = 0; e < EPO; e += 4) {
-                const float4 t4 = *(const float4*)(sp + e);
-                v[e] = t4.x; v[e + 1] = t4.y; v[e + 2] = t4.z; v[e + 3] = t4.w;
-            }
-            TO* yp = Yb + (long long)m * p.ldy + n;
-            if (vec_ok) {
-                if (Rb) {
-                    const uint4 raw = *(const uint4*)(Rb + (long long)m * p.ldr + n);
-                    const TO* rr = (const TO*)&raw;
+    for (int i = 0; i < WM; ++i) {
 #pragma unroll
-                    for (int e = 0; e < EPO; ++e) v[e] += q3_to_f32(rr[e]);
+        for (int jg = 0; jg < WN; jg += JG) {
+            // phase 1: column-wise math, accumulators -> slab
+            int pcols, ncol0;                              // output columns of this pass and the first one's index
+            if (swiglu) {
+                pcols = SCOLS / 2;
+                ncol0 = (n0 >> 1) + wn * (16 * WN) + (jg >> 1) * 32;
+                if constexpr (JG % 2 == 0) {
+#pragma unroll
+                    for (int j = 0; j < JG; j += 2) {
+                        const int cl = (j >> 1) * 32 + l31;
+                        const int n = ncol0 + cl;
+                        const float sc = (p.scale && n < n_out) ? p.scale[n] : 1.f;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                            slab[row * SLD + cl] = q3_silu(acc[i][jg + j][r]) * acc[i][jg + j + 1][r] * sc;
+                        }
+                    }
                 }
-                if (has_post) {
-#pragma unroll
-                    for (int e = 0; e < EPO; ++e) v[e] = q3_snake<TO>(v[e], p.post_a[n + e], p.post_invb[n + e]);
-                }
-                uint4 outv;
-                TO* oo = (TO*)&outv;
-#pragma unroll
-                for (int e = 0; e < EPO; ++e) oo[e] = q3_from_f32<TO>(v[e]);
-                *(uint4*)yp = outv;
             } else {
+                pcols = SCOLS;
+                ncol0 = n0 + wn * 32 * WN + jg * 32;
 #pragma unroll
-                for (int e = 0; e < EPO; ++e) {
-                    if (n + e < n_out) {
-                        float x = v[e];
-                        if (Rb) x += q3_to_f32(Rb[(long long)m * p.ldr + n + e]);
-                        if (has_post) x = q3_snake<TO>(x, p.post_a[n + e], p.post_invb[n + e]);
-                        yp[e] = q3_from_f32<TO>(x);
+                for (int j = 0; j < JG; ++j) {
+                    const int cl = j * 32 + l31;
+                    const int n = ncol0 + cl;
+                    const bool nv = n < n_out;
+                    const float bias = (obias && nv) ? obias[n] : 0.f;
+                    const float sc = (p.scale && nv && !FUSE2) ? p.scale[n] : 1.f;
+                    float ea = 0.f, eib = 0.f;
+                    if (first_act == Q3_ACT_SNAKE && nv) { ea = p.epi_a[n]; eib = p.epi_invb[n]; }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                        float v = acc[i][jg + j][r] + bias;
+                        if (first_act == Q3_ACT_GELU) v = q3_gelu(v);
+                        else if (first_act == Q3_ACT_SNAKE) v = q3_snake<TO>(v, ea, eib);
+                        else if (first_act == Q3_ACT_CLAMP) v = fminf(1.0f, fmaxf(-1.0f, v));
+                        slab[row * SLD + cl] = v * sc;
                     }
                 }
             }
+            __builtin_amdgcn_wave_barrier();
+            // phase 2: row-wise, 16 bytes per lane: + residual, snake of the consumer, store
+            const int cprw = pcols / EPO;                  // 16-byte pieces per slab row
+            const int mrow0 = m0 + wm * 32 * WM + i * 32;
+            for (int id = lane; id < 32 * cprw; id += 64) {
+                const int row = id / cprw, ch = id - row * cprw;
+                const int m = mrow0 + row, n = ncol0 + ch * EPO;
+                if (m >= p.M || n >= n_out) continue;
+                float v[EPO];
+                const float* sp = slab + row * SLD + ch * EPO;
+#pragma unroll
+                for (int e = 0; e < EPO; e += 4) {
+                    const float4 t4 = *(const float4*)(sp + e);
+                    v[e] = t4.x; v[e + 1] = t4.y; v[e + 2] = t4.z; v[e + 3] = t4.w;
+                }
+                const long long yo = (long long)m * p.ldy + n;
+                if (vec_ok) {
+                    if (Rb) {
+                        const uint4 raw = *(const uint4*)(Rb + (long long)m * p.ldr + n);
+                        const TO* rr = (const TO*)&raw;
+#pragma unroll
+                        for (int e = 0; e < EPO; ++e) v[e] += q3_to_f32(rr[e]);
+                    }
+                    uint4 outv;
+                    TO* oo = (TO*)&outv;
+                    if (Y2b) {
+#pragma unroll
+                        for (int e = 0; e < EPO; ++e) oo[e] = q3_from_f32<TO>(v[e]);
+                        *(uint4*)(Yb + yo) = outv;
+                    }
+                    if (has_post) {
+#pragma unroll
+                        for (int e = 0; e < EPO; ++e) v[e] = q3_snake<TO>(v[e], p.post_a[n + e], p.post_invb[n + e]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < EPO; ++e) oo[e] = q3_from_f32<TO>(v[e]);
+                    *(uint4*)((Y2b ? Y2b : Yb) + yo) = outv;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < EPO; ++e) {
+                        if (n + e < n_out) {
+                            float x = v[e];
+                            if (Rb) x += q3_to_f32(Rb[(long long)m * p.ldr + n + e]);
+                            if (Y2b) Yb[yo + e] = q3_from_f32<TO>(x);
+                            if (has_post) x = q3_snake<TO>(x, p.post_a[n + e], p.post_invb[n + e]);
+                            (Y2b ? Y2b : Yb)[yo + e] = q3_from_f32<TO>(x);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
-template <typename TA, typename TO, int WAVES_M, int WAVES_N, int WM, int WN, int BKB>
+// ---- host side ----------------------------------------------------------------------------------------
+template <typename TA, typename TO, int WAVES_M, int WAVES_N, int WM, int WN, int BKB, bool FUSE2>
 hipError_t launch_cfg(const ConvGemmArgs& a, hipStream_t s) {
     constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
     constexpr int CPR = BKB / 16;
+    constexpr int JG = WN < 3 ? WN : 3;
     const int halo = (a.taps - 1) * a.off_step;
     const int HR = BM + halo;
     const int xi_total = (HR * CPR + 255) / 256;
     const int xps = (xi_total + a.taps - 1) / a.taps;
     if (xps > (BM * CPR + 255) / 256) return hipErrorInvalidValue;      // halo too large for the staged-slice scheme
-    size_t lds = 2 * (size_t)HR * BKB + 2 * (size_t)BN * BKB;
-    const size_t lds_epilogue = (size_t)4 * 32 * (32 * WN + 4) * sizeof(float);      // four wave-private slabs
-    if (lds_epilogue > lds) lds = lds_epilogue;
+    if (FUSE2 && (a.N > BN || !a.W2 || a.act == Q3_ACT_SWIGLU)) return hipErrorInvalidValue;
+    size_t region0 = 2 * round_kb((size_t)HR * BKB);
+    if (FUSE2) region0 = std::max(region0, (size_t)BM * (a.N * sizeof(TA) + 16));
+    size_t lds = round_kb(region0) + 2 * round_kb((size_t)BN * BKB);
+    lds = std::max(lds, (size_t)4 * 32 * (32 * JG + 4) * sizeof(float));     // four wave-private epilogue slabs
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = convgemm_kernel<TA, TO, WAVES_M, WAVES_N, WM, WN, BKB>;
+    auto kern = convgemm_kernel<TA, TO, WAVES_M, WAVES_N, WM, WN, BKB, FUSE2>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -357,35 +536,64 @@ hipError_t launch_cfg(const ConvGemmArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// tile shape selection: 0 = 256x96 tile / 64-byte K rows, 1 = 128x128 / 128-byte, 2 = 128x128 / 64-byte,
-// 3 = 256x32 / 64-byte (outputs of at most 32 channels: the final 1-channel convolution)
+// tile shapes: 0 = 256x96 / 64-byte K rows, 1 = 128x128 / 128-byte, 2 = 128x128 / 64-byte, 3 = 256x32 / 64-byte
+// (outputs of at most 32 channels: the final 1-channel convolution), 4 = 128x192 / 64-byte (fused residual unit of 192
+// channels), 5 = 256x96 fused
+enum { SH_256x96 = 0, SH_128x128_K128, SH_128x128_K64, SH_256x32, SH_F_128x192, SH_F_256x96, SH_F_256x32, SH_COUNT };
+
 int pick_shape(const ConvGemmArgs& a, size_t elem) {
+    if (a.W2) {                                   // fused residual unit: one N tile must hold every channel
+        if (a.N <= 32) return SH_F_256x32;
+        if (a.N <= 96) return SH_F_256x96;
+        if (a.N <= 192) return SH_F_128x192;
+        return -1;
+    }
     const bool wide_k = ((size_t)a.K * elem) % 128 == 0;
-    if (a.N <= 32 && a.act != Q3_ACT_SWIGLU) return 3;
+    if (a.N <= 32 && a.act != Q3_ACT_SWIGLU) return SH_256x32;
     const bool use_96 = (a.act != Q3_ACT_SWIGLU) && (a.N % 128 != 0) && (a.N % 96 == 0) && a.N < 512;
-    return use_96 ? 0 : (wide_k ? 1 : 2);
+    return use_96 ? SH_256x96 : (wide_k ? SH_128x128_K128 : SH_128x128_K64);
 }
 
 template <typename TA, typename TO>
 hipError_t launch_typed(const ConvGemmArgs& a, hipStream_t s) {
     switch (pick_shape(a, sizeof(TA))) {
-        case 0: return launch_cfg<TA, TO, 4, 1, 2, 3, 64>(a, s);
-        case 1: return launch_cfg<TA, TO, 2, 2, 2, 2, 128>(a, s);
-        case 2: return launch_cfg<TA, TO, 2, 2, 2, 2, 64>(a, s);
-        default: return launch_cfg<TA, TO, 4, 1, 2, 1, 64>(a, s);
+        case SH_256x96: return launch_cfg<TA, TO, 4, 1, 2, 3, 64, false>(a, s);
+        case SH_128x128_K128: return launch_cfg<TA, TO, 2, 2, 2, 2, 128, false>(a, s);
+        case SH_128x128_K64: return launch_cfg<TA, TO, 2, 2, 2, 2, 64, false>(a, s);
+        case SH_256x32: return launch_cfg<TA, TO, 4, 1, 2, 1, 64, false>(a, s);
+        case SH_F_128x192: return launch_cfg<TA, TO, 4, 1, 1, 6, 64, true>(a, s);
+        case SH_F_256x96: return launch_cfg<TA, TO, 4, 1, 2, 3, 64, true>(a, s);
+        case SH_F_256x32: return launch_cfg<TA, TO, 4, 1, 2, 1, 64, true>(a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// the fused form exists only where input and output element types agree (it re-reads its input as the residual)
+template <typename TA, typename TO>
+hipError_t launch_typed_nofuse(const ConvGemmArgs& a, hipStream_t s) {
+    switch (pick_shape(a, sizeof(TA))) {
+        case SH_256x96: return launch_cfg<TA, TO, 4, 1, 2, 3, 64, false>(a, s);
+        case SH_128x128_K128: return launch_cfg<TA, TO, 2, 2, 2, 2, 128, false>(a, s);
+        case SH_128x128_K64: return launch_cfg<TA, TO, 2, 2, 2, 2, 64, false>(a, s);
+        case SH_256x32: return launch_cfg<TA, TO, 4, 1, 2, 1, 64, false>(a, s);
+        default: return hipErrorInvalidValue;
     }
 }
 
 }  // namespace
 
+int q3_convgemm_fusable(int N) { return N <= 192; }
+
 const char* q3_convgemm_variant(const ConvGemmArgs& a, int in_dtype, int out_dtype) {
-    static const char* names[4][4] = {
-        {"convgemm<f32,f32,256x96,k64B>", "convgemm<f32,f32,128x128,k128B>", "convgemm<f32,f32,128x128,k64B>", "convgemm<f32,f32,256x32,k64B>"},
-        {"convgemm<bf16,bf16,256x96,k64B>", "convgemm<bf16,bf16,128x128,k128B>", "convgemm<bf16,bf16,128x128,k64B>", "convgemm<bf16,bf16,256x32,k64B>"},
-        {"convgemm<f32,bf16,256x96,k64B>", "convgemm<f32,bf16,128x128,k128B>", "convgemm<f32,bf16,128x128,k64B>", "convgemm<f32,bf16,256x32,k64B>"},
-        {"convgemm<bf16,f32,256x96,k64B>", "convgemm<bf16,f32,128x128,k128B>", "convgemm<bf16,f32,128x128,k64B>", "convgemm<bf16,f32,256x32,k64B>"}};
+    static const char* shapes[SH_COUNT] = {"256x96,k64B", "128x128,k128B", "128x128,k64B", "256x32,k64B",
+                                           "resunit 128x192,k64B", "resunit 256x96,k64B", "resunit 256x32,k64B"};
+    static const char* types[4] = {"f32,f32", "bf16,bf16", "f32,bf16", "bf16,f32"};
+    static char names[4][SH_COUNT][64];
     const int t = (in_dtype == Q3_F32 && out_dtype == Q3_F32) ? 0 : (in_dtype == Q3_BF16 ? (out_dtype == Q3_BF16 ? 1 : 3) : 2);
-    return names[t][pick_shape(a, in_dtype == Q3_BF16 ? 2 : 4)];
+    const int sh = pick_shape(a, in_dtype == Q3_BF16 ? 2 : 4);
+    if (sh < 0) return "convgemm<unsupported>";
+    if (!names[t][sh][0]) snprintf(names[t][sh], sizeof(names[t][sh]), "convgemm<%s,%s>", types[t], shapes[sh]);
+    return names[t][sh];
 }
 
 hipError_t q3_launch_convgemm(const ConvGemmArgs& a, int in_dtype, int out_dtype, hipStream_t s) {
@@ -393,10 +601,12 @@ hipError_t q3_launch_convgemm(const ConvGemmArgs& a, int in_dtype, int out_dtype
     const int epc_in = in_dtype == Q3_BF16 ? 8 : 4;
     if (a.K % epc_in || a.ldx % epc_in || a.x_batch_stride % epc_in || a.taps < 1 || a.off_step < 0)
         return hipErrorInvalidValue;
-    if (((uintptr_t)a.X | (uintptr_t)a.W) & 15) return hipErrorInvalidValue;
+    if (((uintptr_t)a.X | (uintptr_t)a.W | (uintptr_t)a.W2) & 15) return hipErrorInvalidValue;
+    if (a.W2 && (a.N % epc_in)) return hipErrorInvalidValue;
     if (in_dtype == Q3_F32 && out_dtype == Q3_F32) return launch_typed<float, float>(a, s);
     if (in_dtype == Q3_BF16 && out_dtype == Q3_BF16) return launch_typed<bf16, bf16>(a, s);
-    if (in_dtype == Q3_F32 && out_dtype == Q3_BF16) return launch_typed<float, bf16>(a, s);
-    if (in_dtype == Q3_BF16 && out_dtype == Q3_F32) return launch_typed<bf16, float>(a, s);
+    if (a.W2) return hipErrorInvalidValue;
+    if (in_dtype == Q3_F32 && out_dtype == Q3_BF16) return launch_typed_nofuse<float, bf16>(a, s);
+    if (in_dtype == Q3_BF16 && out_dtype == Q3_F32) return launch_typed_nofuse<bf16, float>(a, s);
     return hipErrorInvalidValue;
 }

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -66,7 +67,9 @@ struct q3c_ctx {
 
     // per-kernel timing
     struct ProfRec { hipEvent_t a, b; const char* name; double flops, bytes; };
-    bool profiling = false;
+    bool fuse_units = true;           // residual units of <= 192 channels as one launch
+    bool profiling = false, profile_detail = false;
+    std::set<std::string> interned;
     std::vector<ProfRec> prof;
     std::vector<hipEvent_t> event_pool;
 
@@ -229,6 +232,8 @@ struct GemmOpts {
     const float* scale = nullptr;
     const void* R = nullptr;
     const Snake* post = nullptr;
+    void* Y2 = nullptr;               // second output: Y gets the pre-`post` value, Y2 the post value
+    const GemmW* second = nullptr;    // fused 1x1 second contraction (residual unit in one launch)
 };
 
 // X [B][L_in][K] contiguous -> Y [B][M][N_out] contiguous (N_out = N, or N/2 for SwiGLU); R like Y.
@@ -247,10 +252,21 @@ int gemm(q3c_ctx* c, const GemmW& g, const void* X, int B, int L_in, void* Y, in
     if (o.epi) { a.epi_a = o.epi->a; a.epi_invb = o.epi->invb; }
     a.scale = o.scale;
     if (o.post) { a.post_a = o.post->a; a.post_invb = o.post->invb; }
+    a.Y2 = o.Y2;
+    if (o.second) { a.W2 = o.second->w; a.bias2 = o.second->bias; }
     if (g.taps == 1 && M == L_in) {      // no halo: batch items are just more rows
         a.M = B * M; a.L_in = B * L_in; a.B = 1;
     }
-    ProfScope ps(c, s, c->profiling ? q3_convgemm_variant(a, g.in_dtype, out_dtype) : "", 2.0 * a.B * a.M * (double)a.N * a.K * a.taps, 0.0);
+    const char* pname = "";
+    if (c->profiling) {
+        pname = q3_convgemm_variant(a, g.in_dtype, out_dtype);
+        if (c->profile_detail) {      // one entry per layer shape: interned so the pointer outlives this call
+            char buf[64];
+            std::snprintf(buf, sizeof(buf), "%.24s M%dxN%dxK%dxT%d%s", pname + 9, a.B * a.M, a.N, a.K, a.taps, o.pro ? "+pro" : "");
+            pname = c->interned.insert(buf).first->c_str();
+        }
+    }
+    ProfScope ps(c, s, pname, 2.0 * a.B * a.M * (double)a.N * (a.K * a.taps + (o.second ? a.N : 0)), 0.0);
     hipError_t e = q3_launch_convgemm(a, g.in_dtype, out_dtype, s);
     if (e != hipSuccess) return fail(c, Q3C_ERR_HIP, std::string("convgemm launch: ") + hipGetErrorString(e));
     return 0;
@@ -677,6 +693,7 @@ int q3c_forward(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, float* w
         TRY(tap_out(c, Q3C_STAGE_CONV_IN, cur, (size_t)B * L * k.decoder_dim, s));
     }
     int ch = k.decoder_dim;
+    void* scratch = bufC;
     for (size_t i = 0; i < c->blocks.size(); ++i) {
         const Block& b = c->blocks[i];
         if (L < 2) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "sequence too short for the transposed convolutions");
@@ -684,16 +701,27 @@ int q3c_forward(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, float* w
         ch /= 2;
         TRY(gemm(c, b.tconv, cur, B, L, other, Lq, dt, GemmOpts{}, s));       // [B, L-1, r*ch] == [B, (L-1)*r, ch]
         L = Lq * b.rate;
-        void* t = other; void* hh = bufC;
+        void* t = other; void* hh = scratch;
+        const bool fuse = c->fuse_units && q3_convgemm_fusable(ch);
         for (size_t j = 0; j < b.units.size(); ++j) {
             const Unit& u = b.units[j];
-            GemmOpts g1; g1.pro = &u.a1; g1.act = Q3_ACT_SNAKE; g1.epi = &u.a2;
-            TRY(gemm(c, u.c1, t, B, L, hh, L, dt, g1, s));
-            GemmOpts g2; g2.R = t;
-            if (j + 1 == b.units.size()) g2.post = (i + 1 < c->blocks.size()) ? &c->blocks[i + 1].head : &c->final_snake;
-            TRY(gemm(c, u.c2, hh, B, L, t, L, dt, g2, s));
+            const Snake* post = nullptr;
+            if (j + 1 == b.units.size()) post = (i + 1 < c->blocks.size()) ? &c->blocks[i + 1].head : &c->final_snake;
+            if (fuse) {
+                // snake -> conv k7 -> snake -> conv k1 -> + x in one launch; it reads its input with a halo, so it
+                // cannot run in place: the unit's output goes to the spare arena and the two swap roles
+                GemmOpts g; g.pro = &u.a1; g.act = Q3_ACT_SNAKE; g.epi = &u.a2; g.second = &u.c2; g.R = t; g.post = post;
+                TRY(gemm(c, u.c1, t, B, L, hh, L, dt, g, s));
+                std::swap(t, hh);
+            } else {
+                GemmOpts g1; g1.pro = &u.a1; g1.act = Q3_ACT_SNAKE; g1.epi = &u.a2;
+                TRY(gemm(c, u.c1, t, B, L, hh, L, dt, g1, s));
+                GemmOpts g2; g2.R = t; g2.post = post;
+                TRY(gemm(c, u.c2, hh, B, L, t, L, dt, g2, s));
+            }
         }
-        std::swap(cur, other);
+        // the block's output is in `t`; the block's input arena and the other one become free
+        { void* in = cur; cur = t; other = in; scratch = hh; }
         TRY(tap_out(c, Q3C_STAGE_BLOCK0 + (int)i, cur, (size_t)B * L * ch, s));
     }
     {   // final conv to one channel, clamp fused, fp32 samples out
@@ -708,6 +736,7 @@ int q3c_profile_enable(q3c_ctx* c, int32_t on) {
     for (auto& r : c->prof) { c->event_pool.push_back(r.a); c->event_pool.push_back(r.b); }
     c->prof.clear();
     c->profiling = on != 0;
+    c->profile_detail = on == 2;      // 2: one entry per (kernel, layer shape)
     return 0;
 }
 

@@ -241,13 +241,14 @@ class Decoder:
         return [host[s:s + n].copy() for s, n in zip(starts, lengths)], self.cfg.sample_rate
 
     # ------------------------------------------------------------------------------------------------
-    def profile(self, on: bool) -> None:
-        """Bracket every kernel launch of the following forwards with HIP events (see q3c_profile_enable)."""
-        self._check(self._lib.q3c_profile_enable(self._ctx, 1 if on else 0))
+    def profile(self, on: bool, detail: bool = False) -> None:
+        """Bracket every kernel launch of the following forwards with HIP events (see q3c_profile_enable);
+        detail=True keeps one entry per (kernel, layer shape) instead of one per kernel."""
+        self._check(self._lib.q3c_profile_enable(self._ctx, (2 if detail else 1) if on else 0))
 
     def profile_read(self) -> List[dict]:
         """Per-kernel launches, summed milliseconds and algorithmic flops / bytes since profile(True)."""
-        cap = 64
+        cap = 512
         arr = (_lib.Q3cProfileEntry * cap)()
         n = C.c_int32()
         self._check(self._lib.q3c_profile_read(self._ctx, arr, cap, C.byref(n)))
