@@ -25,7 +25,10 @@ struct Snake { float* a = nullptr; float* invb = nullptr; int C = 0; };
 struct Layer { float* ln1; float* ln2; GemmW qkv, o, gu, down; float* ls_attn; float* ls_mlp; };
 struct UpStage { GemmW tconv; int f; float *dw_w, *dw_b, *ln_w, *ln_b; GemmW pw1, pw2; float* gamma; };
 struct Unit { Snake a1, a2; GemmW c1, c2; };
-struct Block { Snake head; GemmW tconv; int rate; std::vector<Unit> units; };
+struct Block {
+    Snake head; GemmW tconv; int rate; std::vector<Unit> units;
+    Snake first_act_tiled;     // units[0].a1 repeated `rate` times: the transposed conv's columns are (phase, channel)
+};
 
 uint16_t f32_to_bf16(float f) {
     uint32_t u; std::memcpy(&u, &f, 4);
@@ -212,11 +215,14 @@ int pack_snake_host(q3c_ctx* c, const float* alpha, const float* beta, int C, fl
     if ((rc = upload_f32(c, va, &s->a))) return rc;
     return upload_f32(c, vb, &s->invb);
 }
-int pack_snake(q3c_ctx* c, const std::string& prefix, int C, Snake* s) {
+int pack_snake(q3c_ctx* c, const std::string& prefix, int C, Snake* s, int repeat = 1) {
     int rc = 0;
     GETW(a, prefix + "alpha", C);
     GETW(b, prefix + "beta", C);
-    return pack_snake_host(c, a->data.data(), b->data.data(), C, c->cfg.snake_eps, s);
+    if (repeat == 1) return pack_snake_host(c, a->data.data(), b->data.data(), C, c->cfg.snake_eps, s);
+    std::vector<float> ta, tb;
+    for (int r = 0; r < repeat; ++r) { ta.insert(ta.end(), a->data.begin(), a->data.end()); tb.insert(tb.end(), b->data.begin(), b->data.end()); }
+    return pack_snake_host(c, ta.data(), tb.data(), C * repeat, c->cfg.snake_eps, s);
 }
 int pack_vec(q3c_ctx* c, const std::string& name, int n, float** out) {
     int rc = 0;
@@ -274,8 +280,8 @@ int gemm(q3c_ctx* c, const GemmW& g, const void* X, int B, int L_in, void* Y, in
 
 // ---- workspace layout -----------------------------------------------------------------------------------
 struct Layout {
-    size_t S = 0, Qb = 0, A = 0, Bq = 0, C = 0;           // region sizes in bytes
-    size_t oS = 0, oQ = 0, oA = 0, oB = 0, oC = 0, total = 0;
+    size_t S = 0, Qb = 0, A = 0, Bq = 0, C = 0, D = 0;    // region sizes in bytes
+    size_t oS = 0, oQ = 0, oA = 0, oB = 0, oC = 0, oD = 0, total = 0;
 };
 
 // Walks the stage sequence of forward() and records the largest tenant of every region.
@@ -306,11 +312,12 @@ Layout make_layout(const q3c_ctx* c, int B, int T) {
         L = (L - 1) * k.upsample_rates[i];
         ch /= 2;
         size_t bytes = (size_t)B * L * ch * es;
-        mx(l.A, bytes); mx(l.Bq, bytes); mx(l.C, bytes);
+        // a block keeps four tensors alive: its input, the raw stream, and two snaked copies that alternate
+        mx(l.A, bytes); mx(l.Bq, bytes); mx(l.C, bytes); mx(l.D, bytes);
     }
-    l.S = align_up(l.S); l.Qb = align_up(l.Qb); l.A = align_up(l.A); l.Bq = align_up(l.Bq); l.C = align_up(l.C);
-    l.oS = 0; l.oQ = l.oS + l.S; l.oA = l.oQ + l.Qb; l.oB = l.oA + l.A; l.oC = l.oB + l.Bq;
-    l.total = l.oC + l.C;
+    l.S = align_up(l.S); l.Qb = align_up(l.Qb); l.A = align_up(l.A); l.Bq = align_up(l.Bq); l.C = align_up(l.C); l.D = align_up(l.D);
+    l.oS = 0; l.oQ = l.oS + l.S; l.oA = l.oQ + l.Qb; l.oB = l.oA + l.A; l.oC = l.oB + l.Bq; l.oD = l.oC + l.C;
+    l.total = l.oD + l.D;
     return l;
 }
 
@@ -551,6 +558,7 @@ int q3c_finalize(q3c_ctx* c) {
             TRY(pack_snake(c, q + "act2.", cout, &u.a2));
             TRY(pack_conv(c, q + "conv2.conv", cout, cout, 1, 1, dt, &u.c2));
         }
+        TRY(pack_snake(c, pre + "2.act1.", cout, &b.first_act_tiled, r));
         ch = cout;
     }
     const int nb = k.num_upsample_rates;
@@ -692,36 +700,46 @@ int q3c_forward(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, float* w
         std::swap(cur, other);
         TRY(tap_out(c, Q3C_STAGE_CONV_IN, cur, (size_t)B * L * k.decoder_dim, s));
     }
+    // Each block: transposed conv, then residual units.  Every tensor a convolution reads is stored already passed
+    // through that convolution's SnakeBeta by whichever kernel produced it (so the inputs need no transform and go
+    // global -> LDS by DMA); the raw residual stream `raw` is kept beside it and updated in place.
     int ch = k.decoder_dim;
-    void* scratch = bufC;
+    void* free_bufs[3] = {other, bufC, base + lay.oD};
     for (size_t i = 0; i < c->blocks.size(); ++i) {
         const Block& b = c->blocks[i];
         if (L < 2) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "sequence too short for the transposed convolutions");
         const int Lq = L - 1;
         ch /= 2;
-        TRY(gemm(c, b.tconv, cur, B, L, other, Lq, dt, GemmOpts{}, s));       // [B, L-1, r*ch] == [B, (L-1)*r, ch]
+        void* raw = free_bufs[0]; void* sn = free_bufs[1]; void* sp = free_bufs[2];
+        {
+            GemmOpts g; g.post = &b.first_act_tiled; g.Y2 = sn;
+            TRY(gemm(c, b.tconv, cur, B, L, raw, Lq, dt, g, s));              // [B, L-1, r*ch] == [B, (L-1)*r, ch]
+        }
         L = Lq * b.rate;
-        void* t = other; void* hh = scratch;
         const bool fuse = c->fuse_units && q3_convgemm_fusable(ch);
         for (size_t j = 0; j < b.units.size(); ++j) {
             const Unit& u = b.units[j];
-            const Snake* post = nullptr;
-            if (j + 1 == b.units.size()) post = (i + 1 < c->blocks.size()) ? &c->blocks[i + 1].head : &c->final_snake;
+            const bool last = j + 1 == b.units.size();
+            const Snake* post = !last ? &b.units[j + 1].a1 : ((i + 1 < c->blocks.size()) ? &c->blocks[i + 1].head : &c->final_snake);
             if (fuse) {
-                // snake -> conv k7 -> snake -> conv k1 -> + x in one launch; it reads its input with a halo, so it
-                // cannot run in place: the unit's output goes to the spare arena and the two swap roles
-                GemmOpts g; g.pro = &u.a1; g.act = Q3_ACT_SNAKE; g.epi = &u.a2; g.second = &u.c2; g.R = t; g.post = post;
-                TRY(gemm(c, u.c1, t, B, L, hh, L, dt, g, s));
-                std::swap(t, hh);
+                // conv k7 -> snake -> conv k1 -> + raw in one launch; it reads `sn` with a halo, so the snaked output
+                // goes to the spare buffer; the raw stream is updated in place (each element is read and written by
+                // the same lane)
+                GemmOpts g; g.act = Q3_ACT_SNAKE; g.epi = &u.a2; g.second = &u.c2; g.R = raw; g.post = post;
+                if (last) { TRY(gemm(c, u.c1, sn, B, L, sp, L, dt, g, s)); }
+                else { g.Y2 = sp; TRY(gemm(c, u.c1, sn, B, L, raw, L, dt, g, s)); }
+                std::swap(sn, sp);
             } else {
-                GemmOpts g1; g1.pro = &u.a1; g1.act = Q3_ACT_SNAKE; g1.epi = &u.a2;
-                TRY(gemm(c, u.c1, t, B, L, hh, L, dt, g1, s));
-                GemmOpts g2; g2.R = t; g2.post = post;
-                TRY(gemm(c, u.c2, hh, B, L, t, L, dt, g2, s));
+                GemmOpts g1; g1.act = Q3_ACT_SNAKE; g1.epi = &u.a2;
+                TRY(gemm(c, u.c1, sn, B, L, sp, L, dt, g1, s));
+                GemmOpts g2; g2.R = raw; g2.post = post;
+                if (last) { TRY(gemm(c, u.c2, sp, B, L, sn, L, dt, g2, s)); }
+                else { g2.Y2 = sn; TRY(gemm(c, u.c2, sp, B, L, raw, L, dt, g2, s)); }
             }
         }
-        // the block's output is in `t`; the block's input arena and the other one become free
-        { void* in = cur; cur = t; other = in; scratch = hh; }
+        // the block's output (next SnakeBeta applied) is in `sn`
+        free_bufs[0] = cur; free_bufs[1] = raw; free_bufs[2] = sp;
+        cur = sn;
         TRY(tap_out(c, Q3C_STAGE_BLOCK0 + (int)i, cur, (size_t)B * L * ch, s));
     }
     {   // final conv to one channel, clamp fused, fp32 samples out
