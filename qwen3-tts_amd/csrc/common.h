@@ -20,10 +20,10 @@ enum Q3Act : int {
     Q3_ACT_CLAMP = 4,   // clamp(x, -1, 1)
 };
 
-// h = scale[n] * act( bias[n] + sum_tap sum_k pro(X[b, m + off0 + tap*off_step, k]) * W[tap][n][k] )
+// h = scale[n] * act( bias[n] + sum_tap sum_k X[b, m + off0 + tap*off_step, k] * W[tap][n][k] )
 // with W2:  h <- bias2[n] + sum_j h[., j] * W2[n][j]     (fused 1x1 second contraction; N == K2, scale unused)
 // y = R[b, m, n] + h;   Y <- post(y), or with Y2:  Y <- y and Y2 <- post(y)
-// rows of X outside [0, L_in) read as zero (before and after `pro`, since pro(0) = 0 for snake).
+// rows of X outside [0, L_in) read as zero.
 struct ConvGemmArgs {
     const void* X;  long long x_batch_stride; int ldx; int L_in;
     const void* W;                       // [taps][N][K]
@@ -32,7 +32,6 @@ struct ConvGemmArgs {
     const void* R;  long long r_batch_stride; int ldr;   // residual, element type = output type, or null
     int B, M, N, K;
     int taps, off0, off_step;
-    const float* pro_a; const float* pro_invb;           // [K] snake on the input, or null
     int act;
     const float* epi_a; const float* epi_invb;           // [N] for Q3_ACT_SNAKE
     const float* scale;                                  // [N_out] or null
@@ -46,7 +45,8 @@ enum Q3Dtype : int { Q3_F32 = 0, Q3_BF16 = 1 };
 // ---- launchers (each returns hipError_t of the launch) -------------------------------------------
 hipError_t q3_launch_convgemm(const ConvGemmArgs& a, int in_dtype, int out_dtype, hipStream_t s);
 const char* q3_convgemm_variant(const ConvGemmArgs& a, int in_dtype, int out_dtype);   // name of the instantiation that would run
-int q3_convgemm_fusable(int N);                      // can a residual unit of N channels run as one fused launch?
+int q3_convgemm_fusable(int N, int dtype);                     // can a residual unit of N channels run as one fused launch?
+void q3_convgemm_set_tuning(int bits);               // A/B switches for measurements (0 = defaults)
 
 hipError_t q3_launch_rvq_gather_sum(const long long* codes, int B, int Q, int T, int bins, int D,
                                     const float* const* tables_dev /*[Q] device array of table pointers*/,

@@ -1,6 +1,6 @@
 // Multi-tap row-shifted GEMM on the gfx950 matrix cores: the one dense-contraction kernel of the decode.
 //
-//   h[b, m, n]   = act( bias[n] + sum_tap sum_k pro(X[b, m + off0 + tap*off_step, k]) * W[tap][n][k] ) * scale[n]
+//   h[b, m, n]   = act( bias[n] + sum_tap sum_k X[b, m + off0 + tap*off_step, k] * W[tap][n][k] ) * scale[n]
 //   FUSE2 only:    h <- bias2[n] + sum_j h[b, m, j] * W2[n][j]                (a second, 1x1 contraction in the same launch)
 //   y            = R[b, m, n] + h
 //   Y <- y (or post(y) when Y2 is null);   Y2 <- post(y)                      (post = SnakeBeta of the consumer)
@@ -10,13 +10,14 @@
 //   ConvTranspose1d(k = 2s, stride s) taps = 2, off0 = 0, off_step = 1, N = s*Cout  (row q of [L-1, s*Cout] IS rows q*s .. q*s+s-1 of [.., Cout])
 //   ConvTranspose1d(k = s,  stride s) taps = 1, N = s*Cout
 //   Linear                            taps = 1
-//   residual unit                     FUSE2: snake -> conv k7 -> snake -> conv k1 -> + x in ONE launch
+//   residual unit                     FUSE2: conv k7 -> snake -> conv k1 -> + x in ONE launch (its input arrives already
+//                                     passed through the unit's first snake by the producing kernel's epilogue)
 //
 // A block owns a BM x BN output tile.  Per K-chunk the (BM + halo) input rows are staged ONCE in LDS and every tap
-// reads them at a row offset, so the im2col matrix never exists.  Weight tiles are staged per (K-chunk, tap) step.
-// Staging is double-buffered one step ahead.  Weights - and inputs that need no transform - go global -> LDS
-// directly (LDS-DMA: `global_load_lds` / `buffer_load ... lds`, 16 bytes per lane), with rows outside the sequence
-// zero-filled by the buffer descriptor's range check; inputs with a SnakeBeta prologue pass through registers.
+// reads them at a row offset, so the im2col matrix never exists.  Weight tiles are staged per (K-chunk, tap) step,
+// two steps ahead in three buffers; the next chunk's input tile arrives in slices spread over the current chunk's
+// steps.  Both go global -> LDS directly (LDS-DMA: `global_load_lds` / `buffer_load ... lds`, 16 bytes per lane), rows
+// outside the sequence zero-filled by the buffer descriptor's range check; each wave waits with a counted vmcnt.
 // LDS rows are BKB bytes; 16-byte chunk c of row r sits at slot c ^ f(r), so the 16-lane groups of ds_read_b128 touch
 // 16 distinct slots; with LDS-DMA the destination is lane-linear and the XOR is applied to the SOURCE address.
 //
@@ -53,38 +54,38 @@ template <> struct Mma<float> {
     }
 };
 
-// snake on one 16-byte piece
-template <typename TA> __device__ __forceinline__ uint4 snake_piece(uint4 v, const float* a, const float* ib);
-template <> __device__ __forceinline__ uint4 snake_piece<float>(uint4 v, const float* a, const float* ib) {
-    float x0 = __builtin_bit_cast(float, v.x), x1 = __builtin_bit_cast(float, v.y);
-    float x2 = __builtin_bit_cast(float, v.z), x3 = __builtin_bit_cast(float, v.w);
-    x0 = q3_snake<float>(x0, a[0], ib[0]); x1 = q3_snake<float>(x1, a[1], ib[1]);
-    x2 = q3_snake<float>(x2, a[2], ib[2]); x3 = q3_snake<float>(x3, a[3], ib[3]);
-    return make_uint4(__builtin_bit_cast(unsigned, x0), __builtin_bit_cast(unsigned, x1),
-                      __builtin_bit_cast(unsigned, x2), __builtin_bit_cast(unsigned, x3));
-}
-template <> __device__ __forceinline__ uint4 snake_piece<bf16>(uint4 v, const float* a, const float* ib) {
-    bf16x8 h = __builtin_bit_cast(bf16x8, v);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) h[e] = (bf16)q3_snake<bf16>((float)h[e], a[e], ib[e]);
-    return __builtin_bit_cast(uint4, h);
-}
-
 __host__ __device__ constexpr size_t round_kb(size_t v) { return (v + 1023) / 1024 * 1024; }
 
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n: all but the n youngest vector-memory operations are done.
+__device__ __forceinline__ void wait_vmcnt(int n) {
+    switch (n) {
+#define Q3_VM(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+        Q3_VM(0) Q3_VM(1) Q3_VM(2) Q3_VM(3) Q3_VM(4) Q3_VM(5) Q3_VM(6) Q3_VM(7) Q3_VM(8) Q3_VM(9) Q3_VM(10) Q3_VM(11)
+        Q3_VM(12) Q3_VM(13) Q3_VM(14) Q3_VM(15) Q3_VM(16) Q3_VM(17) Q3_VM(18) Q3_VM(19) Q3_VM(20) Q3_VM(21) Q3_VM(22) Q3_VM(23)
+#undef Q3_VM
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // more than we count: drain
+    }
+}
+__device__ __forceinline__ void block_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 template <typename TA, typename TO, int WAVES_M, int WAVES_N, int WM, int WN, int BKB, bool FUSE2>
-__global__ void __launch_bounds__(256) convgemm_kernel(const ConvGemmArgs p) {
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const ConvGemmArgs p) {
+    constexpr int NW = WAVES_M * WAVES_N;            // waves per block
+    constexpr int NTHR = 64 * NW;
     constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
     constexpr int CPR = BKB / 16;                    // 16-byte chunks per LDS row
     constexpr int EPC = ElemTraits<TA>::EPC;         // elements per chunk
     constexpr int BK = CPR * EPC;                    // K elements per chunk row
     constexpr int KG = BKB / 32;                     // fragment groups per step
-    constexpr int NTHR = 256;
     constexpr int WPIECES = BN * CPR;
     constexpr int WITER = (WPIECES + NTHR - 1) / NTHR;
     constexpr int MAX_XPS = (BM * CPR + NTHR - 1) / NTHR;
     constexpr size_t WBUF = round_kb((size_t)BN * BKB);
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per block");
     static_assert(NTHR % CPR == 0, "column chunk of a thread is fixed");
     static_assert(!FUSE2 || WAVES_N == 1, "the fused second contraction needs whole rows per wave");
 
@@ -105,19 +106,18 @@ __global__ void __launch_bounds__(256) convgemm_kernel(const ConvGemmArgs p) {
     const int xi_total = (xpieces + NTHR - 1) / NTHR;
     const int xps = (xi_total + p.taps - 1) / p.taps;   // pieces per thread per step (<= MAX_XPS, host-checked)
     const size_t XBUF = round_kb((size_t)HR * BKB);
-    const size_t region0 = FUSE2 ? (2 * XBUF > (size_t)BM * (p.N * sizeof(TA) + 16) ? 2 * XBUF : (size_t)BM * (p.N * sizeof(TA) + 16))
-                                 : 2 * XBUF;
+    const size_t hs_bytes = (size_t)BM * (p.N * sizeof(TA) + 16);
+    const size_t region0 = (FUSE2 && hs_bytes > 2 * XBUF) ? hs_bytes : 2 * XBUF;
 
-    unsigned char* Xs0 = smem;
-    unsigned char* Ws0 = smem + round_kb(region0);
+    unsigned char* Xs0 = smem;                       // two input buffers
+    unsigned char* Ws0 = smem + round_kb(region0);   // three weight buffers
 
     const TA* __restrict__ Xb = (const TA*)p.X + (long long)b * p.x_batch_stride;
+    const TA* __restrict__ Wg = (const TA*)p.W;
     const int nkc = (p.K + BK - 1) / BK;
     const int nsteps = nkc * p.taps;
     const int my_c = tid % CPR;                      // column chunk of every piece this thread stages
-    const bool has_pro = p.pro_a != nullptr;
-    const bool w_dma = (p.K % BK) == 0;              // whole chunks only: LDS-DMA cannot zero-fill a K tail
-    const bool x_dma = w_dma && !has_pro;
+    const bool dma = (p.K % BK) == 0;                // whole chunks only: LDS-DMA cannot zero-fill a K tail
 
     // buffer descriptor over the rows of X this tile may touch; anything else reads as zero
     const int g0 = m0 + p.off0;
@@ -127,19 +127,7 @@ __global__ void __launch_bounds__(256) convgemm_kernel(const ConvGemmArgs p) {
     const __amdgpu_buffer_rsrc_t xrsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)(Xb + (long long)r_lo * p.ldx), 0, (int)xrec, 0x00020000);
 
-    float pa[EPC], pib[EPC];
-    auto load_pro = [&](int kc) {
-        if (has_pro) {
-            int k = kc * BK + my_c * EPC;
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                bool ok = (k + e) < p.K;
-                pa[e] = ok ? p.pro_a[k + e] : 0.f;
-                pib[e] = ok ? p.pro_invb[k + e] : 0.f;
-            }
-        }
-    };
-    // ---- input tile, register path ----
+    // ---- input tile, register path (K tail only) ----
     auto x_load = [&](int id, int kc) -> uint4 {
         int row = id / CPR;
         int grow = g0 + row;
@@ -152,28 +140,29 @@ __global__ void __launch_bounds__(256) convgemm_kernel(const ConvGemmArgs p) {
     auto x_store = [&](unsigned char* xs, int id, uint4 v) {
         if (id < xpieces) {
             int row = id / CPR;
-            if (has_pro) v = snake_piece<TA>(v, pa, pib);
             *(uint4*)(xs + (size_t)row * BKB + swz<CPR>(row, my_c) * 16) = v;
         }
     };
-    // ---- input tile, LDS-DMA path: iteration `it` of wave w writes the 1 KiB at (it*4 + w) KiB of the buffer ----
-    auto x_dma_issue = [&](unsigned char* xs, int it, int kc) {
-        if ((it * 4 + wave) * 64 >= xpieces) return;             // wave-uniform: this wave's 1 KiB lies past the tile
+    // ---- input tile, LDS-DMA: iteration `it` of wave w writes the 1 KiB at (it*NW + w) KiB of the buffer; returns the
+    //      number of DMA instructions this wave issued (wave-uniform) ----
+    auto x_dma_issue = [&](unsigned char* xs, int it, int kc) -> int {
+        if ((it * NW + wave) * 64 >= xpieces) return 0;          // this wave's 1 KiB lies past the tile
         const int id = tid + it * NTHR;
         const int row = id / CPR;
         const int c = swz<CPR>(row, my_c);                       // slot my_c of this row must receive chunk c
         long long off = ((long long)(g0 + row - r_lo) * p.ldx + kc * BK + c * EPC) * (int)sizeof(TA);
         unsigned voff = (id < xpieces && off >= 0 && off < xrec) ? (unsigned)off : 0x7fffff00u;   // out of range -> zeros
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)(xs + (size_t)(it * 4 + wave) * 1024), 16, voff, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)(xs + (size_t)(it * NW + wave) * 1024), 16, voff, 0, 0, 0);
+        return 1;
     };
     // ---- weight tile ----
-    auto w_load = [&](const TA* Wg, int ldw, int id, int kc, int tap) -> uint4 {
+    auto w_load = [&](const TA* W, int ldw, int id, int kc, int tap) -> uint4 {
         int row = id / CPR, c = id % CPR;
         int n = n0 + row;
         int kel = kc * BK + c * EPC;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (id < WPIECES && n < p.N && kel < ldw)
-            v = *(const uint4*)(Wg + ((long long)tap * p.N + n) * ldw + kel);
+            v = *(const uint4*)(W + ((long long)tap * p.N + n) * ldw + kel);
         return v;
     };
     auto w_store = [&](unsigned char* ws, int id, uint4 v) {
@@ -182,19 +171,22 @@ __global__ void __launch_bounds__(256) convgemm_kernel(const ConvGemmArgs p) {
             *(uint4*)(ws + (size_t)row * BKB + swz<CPR>(row, c) * 16) = v;
         }
     };
-    auto w_dma_issue = [&](unsigned char* ws, const TA* Wg, int ldw, int kc, int tap) {
+    auto w_dma_issue = [&](unsigned char* ws, const TA* W, int ldw, int kc, int tap) -> int {
+        int issued = 0;
 #pragma unroll
         for (int q = 0; q < WITER; ++q) {
-            if ((q * 4 + wave) * 64 < WPIECES) {                 // wave-uniform
-                const int id = (q * 4 + wave) * 64 + lane;
+            if ((q * NW + wave) * 64 < WPIECES) {                // wave-uniform
+                const int id = (q * NW + wave) * 64 + lane;
                 const int row = id / CPR, cs = id % CPR;
                 const int c = swz<CPR>(row, cs);
                 int n = n0 + row;
                 n = n < p.N ? n : p.N - 1;                       // columns past N are never stored: any finite row will do
-                const TA* src = Wg + ((long long)tap * p.N + n) * ldw + kc * BK + c * EPC;
-                __builtin_amdgcn_global_load_lds((global_cvoid*)src, (lds_void*)(ws + (size_t)(q * 4 + wave) * 1024), 16, 0, 0);
+                const TA* src = W + ((long long)tap * p.N + n) * ldw + kc * BK + c * EPC;
+                __builtin_amdgcn_global_load_lds((global_cvoid*)src, (lds_void*)(ws + (size_t)(q * NW + wave) * 1024), 16, 0, 0);
+                ++issued;
             }
         }
+        return issued;
     };
 
     f32x16 acc[WM][WN];
@@ -205,71 +197,9 @@ __global__ void __launch_bounds__(256) convgemm_kernel(const ConvGemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const TA* __restrict__ Wg = (const TA*)p.W;
-
-    // ---- prologue: whole X tile of chunk 0, W tile of step 0 -------------------------------------
-    if (x_dma) {
-        for (int it = 0; it < xi_total; ++it) x_dma_issue(Xs0, it, 0);
-    } else {
-        load_pro(0);
-        for (int it = 0; it < xi_total; ++it) {
-            int id = tid + it * NTHR;
-            x_store(Xs0, id, x_load(id, 0));
-        }
-        load_pro(1);
-    }
-    if (w_dma) {
-        w_dma_issue(Ws0, Wg, p.K, 0, 0);
-    } else {
-#pragma unroll
-        for (int it = 0; it < WITER; ++it) {
-            int id = tid + it * NTHR;
-            w_store(Ws0, id, w_load(Wg, p.K, id, 0, 0));
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    int kc = 0, tap = 0;
-    for (int step = 0; step < nsteps; ++step) {
-        int ntap = tap + 1, nkc_ = kc;
-        if (ntap == p.taps) { ntap = 0; nkc_ = kc + 1; }
-        const bool has_next = (step + 1) < nsteps;
-        const bool x_next = (kc + 1) < nkc;
-        unsigned char* wsn = Ws0 + (size_t)((step + 1) & 1) * WBUF;
-        unsigned char* xsn = Xs0 + (size_t)((kc + 1) & 1) * XBUF;
-
-        // issue next step's loads: straight into the other LDS buffers, or into registers
-        uint4 wreg[WITER];
-        uint4 xreg[MAX_XPS];
-        if (has_next) {
-            if (w_dma) {
-                w_dma_issue(wsn, Wg, p.K, nkc_, ntap);
-            } else {
-#pragma unroll
-                for (int it = 0; it < WITER; ++it) wreg[it] = w_load(Wg, p.K, tid + it * NTHR, nkc_, ntap);
-            }
-        }
-        if (x_next) {
-            if (x_dma) {
-#pragma unroll
-                for (int i = 0; i < MAX_XPS; ++i) {
-                    int it = tap * xps + i;
-                    if (i < xps && it < xi_total) x_dma_issue(xsn, it, kc + 1);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < MAX_XPS; ++i) {
-                    int it = tap * xps + i;
-                    xreg[i] = (i < xps && it < xi_total) ? x_load(tid + it * NTHR, kc + 1) : make_uint4(0, 0, 0, 0);
-                }
-            }
-        }
-
-        // MFMAs of this step
-        const unsigned char* xs = Xs0 + (size_t)(kc & 1) * XBUF;
-        const unsigned char* ws = Ws0 + (size_t)(step & 1) * WBUF;
-        const int arow0 = wm * 32 * WM + (lane & 31) + tap * p.off_step;
+    // MFMAs of one step: every wave multiplies its rows of the staged input (shifted by the tap) with the weight tile
+    auto compute = [&](const unsigned char* xs, const unsigned char* ws, int row_shift) {
+        const int arow0 = wm * 32 * WM + (lane & 31) + row_shift;
         const int brow0 = wn * 32 * WN + (lane & 31);
 #pragma unroll
         for (int kg = 0; kg < KG; ++kg) {
@@ -285,28 +215,61 @@ __global__ void __launch_bounds__(256) convgemm_kernel(const ConvGemmArgs p) {
                 int row = brow0 + j * 32;
                 bfr[j] = *(const uint4*)(ws + (size_t)row * BKB + swz<CPR>(row, c) * 16);
             }
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j) Mma<TA>::run(af[i], bfr[j], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
         }
+    };
 
-        // land the register-staged tiles in the other buffers
-        if (has_next && !w_dma) {
+    if (dma) {
+        // ---- LDS-DMA pipeline: weight tiles two steps ahead in three buffers, the next chunk's input tile in slices
+        //      spread over this chunk's steps.  Each wave counts its own DMA instructions and waits with vmcnt(n) for all
+        //      but those that may stay in flight; one raw barrier per step.
+        for (int it = 0; it < xi_total; ++it) x_dma_issue(Xs0, it, 0);
+        w_dma_issue(Ws0, Wg, p.K, 0, 0);
+        int ahead = 0;
+        if (nsteps > 1) ahead = w_dma_issue(Ws0 + WBUF, Wg, p.K, p.taps > 1 ? 0 : 1, p.taps > 1 ? 1 : 0);
+        wait_vmcnt(ahead);
+        block_barrier();
+        int kc = 0, tap = 0, wb = 0;                             // wb: weight buffer of the current step
+        for (int step = 0; step < nsteps; ++step) {
+            int ntap = tap + 1, nkc_ = kc;
+            if (ntap == p.taps) { ntap = 0; nkc_ = kc + 1; }
+            int ntap2 = ntap + 1, nkc2 = nkc_;
+            if (ntap2 == p.taps) { ntap2 = 0; nkc2 = nkc_ + 1; }
+            const int wb1 = wb == 2 ? 0 : wb + 1, wb2 = wb1 == 2 ? 0 : wb1 + 1;
+            int nx = 0, nw = 0;
+            if (kc + 1 < nkc) {
+                unsigned char* xsn = Xs0 + (size_t)((kc + 1) & 1) * XBUF;
 #pragma unroll
-            for (int it = 0; it < WITER; ++it) w_store(wsn, tid + it * NTHR, wreg[it]);
-        }
-        if (x_next && !x_dma) {
-#pragma unroll
-            for (int i = 0; i < MAX_XPS; ++i) {
-                int it = tap * xps + i;
-                if (i < xps && it < xi_total) x_store(xsn, tid + it * NTHR, xreg[i]);
+                for (int i = 0; i < MAX_XPS; ++i) {
+                    int it = tap * xps + i;
+                    if (i < xps && it < xi_total) nx += x_dma_issue(xsn, it, kc + 1);
+                }
             }
+            if (step + 2 < nsteps) nw = w_dma_issue(Ws0 + (size_t)wb2 * WBUF, Wg, p.K, nkc2, ntap2);
+            compute(Xs0 + (size_t)(kc & 1) * XBUF, Ws0 + (size_t)wb * WBUF, tap * p.off_step);
+            // next step needs weight tile step+1 (issued one step ago) and, when it opens a new chunk, every input slice
+            wait_vmcnt(ntap == 0 ? nw : nx + nw);
+            block_barrier();
+            tap = ntap; kc = nkc_; wb = wb1;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (ntap == 0 && !x_dma) load_pro(nkc_ + 1);   // parameters for the tile staged during the next chunk's steps
-        tap = ntap; kc = nkc_;
+    } else {
+        // ---- K tail (narrow test shapes): synchronous register staging, zero-filled past K ----
+        int kc = 0, tap = 0;
+        for (int step = 0; step < nsteps; ++step) {
+            if (tap == 0)
+                for (int it = 0; it < xi_total; ++it) x_store(Xs0, tid + it * NTHR, x_load(tid + it * NTHR, kc));
+#pragma unroll
+            for (int it = 0; it < WITER; ++it) w_store(Ws0, tid + it * NTHR, w_load(Wg, p.K, tid + it * NTHR, kc, tap));
+            __syncthreads();
+            compute(Xs0, Ws0, tap * p.off_step);
+            __syncthreads();
+            if (++tap == p.taps) { tap = 0; ++kc; }
+        }
     }
 
     const int half = lane >> 5, l31 = lane & 31;
@@ -316,7 +279,7 @@ __global__ void __launch_bounds__(256) convgemm_kernel(const ConvGemmArgs p) {
         const int HLD = p.N * (int)sizeof(TA) + 16;                 // padded row stride of the h tile
         unsigned char* Hs = smem;                                   // overlays the (now idle) input buffers
         const TA* __restrict__ W2 = (const TA*)p.W2;
-        const bool w2_dma = (p.N % BK) == 0;
+        const bool w2_dma = (p.N % BK) == 0;      // the h tile is consumed in whole chunks too
         // first W2 tile in flight while h is produced
         if (w2_dma) w_dma_issue(Ws0, W2, p.N, 0, 0);
         else {
@@ -508,21 +471,24 @@ __global__ void __launch_bounds__(256) convgemm_kernel(const ConvGemmArgs p) {
 }
 
 // ---- host side ----------------------------------------------------------------------------------------
+int g_tuning = 0;     // bit 0: 4-wave 128x128 tiles instead of 8-wave 256x128 for the wide layers
+
 template <typename TA, typename TO, int WAVES_M, int WAVES_N, int WM, int WN, int BKB, bool FUSE2>
 hipError_t launch_cfg(const ConvGemmArgs& a, hipStream_t s) {
+    constexpr int NW = WAVES_M * WAVES_N, NTHR = 64 * NW;
     constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
     constexpr int CPR = BKB / 16;
     constexpr int JG = WN < 3 ? WN : 3;
     const int halo = (a.taps - 1) * a.off_step;
     const int HR = BM + halo;
-    const int xi_total = (HR * CPR + 255) / 256;
+    const int xi_total = (HR * CPR + NTHR - 1) / NTHR;
     const int xps = (xi_total + a.taps - 1) / a.taps;
-    if (xps > (BM * CPR + 255) / 256) return hipErrorInvalidValue;      // halo too large for the staged-slice scheme
+    if (xps > (BM * CPR + NTHR - 1) / NTHR) return hipErrorInvalidValue;      // halo too large for the staged-slice scheme
     if (FUSE2 && (a.N > BN || !a.W2 || a.act == Q3_ACT_SWIGLU)) return hipErrorInvalidValue;
     size_t region0 = 2 * round_kb((size_t)HR * BKB);
     if (FUSE2) region0 = std::max(region0, (size_t)BM * (a.N * sizeof(TA) + 16));
-    size_t lds = round_kb(region0) + 2 * round_kb((size_t)BN * BKB);
-    lds = std::max(lds, (size_t)4 * 32 * (32 * JG + 4) * sizeof(float));     // four wave-private epilogue slabs
+    size_t lds = round_kb(region0) + 3 * round_kb((size_t)BN * BKB);
+    lds = std::max(lds, (size_t)NW * 32 * (32 * JG + 4) * sizeof(float));    // wave-private epilogue slabs
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     auto kern = convgemm_kernel<TA, TO, WAVES_M, WAVES_N, WM, WN, BKB, FUSE2>;
     if (lds > 48 * 1024) {
@@ -532,61 +498,58 @@ hipError_t launch_cfg(const ConvGemmArgs& a, hipStream_t s) {
     const long long tiles = (long long)((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM);
     if (tiles > 0x7fffffffLL || a.B > 65535) return hipErrorInvalidValue;
     dim3 grid((unsigned)tiles, a.B, 1);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, grid, dim3(NTHR), lds, s, a);
     return hipGetLastError();
 }
 
-// tile shapes: 0 = 256x96 / 64-byte K rows, 1 = 128x128 / 128-byte, 2 = 128x128 / 64-byte, 3 = 256x32 / 64-byte
-// (outputs of at most 32 channels: the final 1-channel convolution), 4 = 128x192 / 64-byte (fused residual unit of 192
-// channels), 5 = 256x96 fused
-enum { SH_256x96 = 0, SH_128x128_K128, SH_128x128_K64, SH_256x32, SH_F_128x192, SH_F_256x96, SH_F_256x32, SH_COUNT };
+// tile shapes (rows x columns, K-row bytes, waves)
+enum { SH_256x96 = 0, SH_256x128_K128, SH_128x128_K128, SH_128x128_K64, SH_256x32, SH_F_256x192, SH_F_256x96, SH_F_256x32, SH_COUNT };
 
 int pick_shape(const ConvGemmArgs& a, size_t elem) {
     if (a.W2) {                                   // fused residual unit: one N tile must hold every channel
         if (a.N <= 32) return SH_F_256x32;
         if (a.N <= 96) return SH_F_256x96;
-        if (a.N <= 192) return SH_F_128x192;
+        if (a.N <= 192) return SH_F_256x192;
         return -1;
     }
     const bool wide_k = ((size_t)a.K * elem) % 128 == 0;
     if (a.N <= 32 && a.act != Q3_ACT_SWIGLU) return SH_256x32;
     const bool use_96 = (a.act != Q3_ACT_SWIGLU) && (a.N % 128 != 0) && (a.N % 96 == 0) && a.N < 512;
-    return use_96 ? SH_256x96 : (wide_k ? SH_128x128_K128 : SH_128x128_K64);
+    if (use_96) return SH_256x96;
+    if (!wide_k) return SH_128x128_K64;
+    return (g_tuning & 1) ? SH_128x128_K128 : SH_256x128_K128;
 }
 
-template <typename TA, typename TO>
+template <typename TA, typename TO, bool ALLOW_FUSE>
 hipError_t launch_typed(const ConvGemmArgs& a, hipStream_t s) {
     switch (pick_shape(a, sizeof(TA))) {
         case SH_256x96: return launch_cfg<TA, TO, 4, 1, 2, 3, 64, false>(a, s);
+        case SH_256x128_K128: return launch_cfg<TA, TO, 4, 2, 2, 2, 128, false>(a, s);
         case SH_128x128_K128: return launch_cfg<TA, TO, 2, 2, 2, 2, 128, false>(a, s);
         case SH_128x128_K64: return launch_cfg<TA, TO, 2, 2, 2, 2, 64, false>(a, s);
         case SH_256x32: return launch_cfg<TA, TO, 4, 1, 2, 1, 64, false>(a, s);
-        case SH_F_128x192: return launch_cfg<TA, TO, 4, 1, 1, 6, 64, true>(a, s);
-        case SH_F_256x96: return launch_cfg<TA, TO, 4, 1, 2, 3, 64, true>(a, s);
-        case SH_F_256x32: return launch_cfg<TA, TO, 4, 1, 2, 1, 64, true>(a, s);
-        default: return hipErrorInvalidValue;
+        default: break;
     }
-}
-
-// the fused form exists only where input and output element types agree (it re-reads its input as the residual)
-template <typename TA, typename TO>
-hipError_t launch_typed_nofuse(const ConvGemmArgs& a, hipStream_t s) {
-    switch (pick_shape(a, sizeof(TA))) {
-        case SH_256x96: return launch_cfg<TA, TO, 4, 1, 2, 3, 64, false>(a, s);
-        case SH_128x128_K128: return launch_cfg<TA, TO, 2, 2, 2, 2, 128, false>(a, s);
-        case SH_128x128_K64: return launch_cfg<TA, TO, 2, 2, 2, 2, 64, false>(a, s);
-        case SH_256x32: return launch_cfg<TA, TO, 4, 1, 2, 1, 64, false>(a, s);
-        default: return hipErrorInvalidValue;
+    if constexpr (ALLOW_FUSE) {      // the fused form re-reads its input's element type as the residual: same-type pairs only
+        switch (pick_shape(a, sizeof(TA))) {
+            case SH_F_256x192: return launch_cfg<TA, TO, 8, 1, 1, 6, 64, true>(a, s);
+            case SH_F_256x96: return launch_cfg<TA, TO, 4, 1, 2, 3, 64, true>(a, s);
+            case SH_F_256x32: return launch_cfg<TA, TO, 4, 1, 2, 1, 64, true>(a, s);
+            default: break;
+        }
     }
+    return hipErrorInvalidValue;
 }
 
 }  // namespace
 
-int q3_convgemm_fusable(int N) { return N <= 192; }
+// the h tile of the fused residual unit (256 rows x N channels of the operand type) must fit LDS beside the weight buffers
+int q3_convgemm_fusable(int N, int dtype) { return N <= (dtype == Q3_BF16 ? 192 : 96); }
+void q3_convgemm_set_tuning(int bits) { g_tuning = bits; }
 
 const char* q3_convgemm_variant(const ConvGemmArgs& a, int in_dtype, int out_dtype) {
-    static const char* shapes[SH_COUNT] = {"256x96,k64B", "128x128,k128B", "128x128,k64B", "256x32,k64B",
-                                           "resunit 128x192,k64B", "resunit 256x96,k64B", "resunit 256x32,k64B"};
+    static const char* shapes[SH_COUNT] = {"256x96,k64B,4w", "256x128,k128B,8w", "128x128,k128B,4w", "128x128,k64B,4w", "256x32,k64B,4w",
+                                           "resunit 256x192,k64B,8w", "resunit 256x96,k64B,4w", "resunit 256x32,k64B,4w"};
     static const char* types[4] = {"f32,f32", "bf16,bf16", "f32,bf16", "bf16,f32"};
     static char names[4][SH_COUNT][64];
     const int t = (in_dtype == Q3_F32 && out_dtype == Q3_F32) ? 0 : (in_dtype == Q3_BF16 ? (out_dtype == Q3_BF16 ? 1 : 3) : 2);
@@ -603,10 +566,9 @@ hipError_t q3_launch_convgemm(const ConvGemmArgs& a, int in_dtype, int out_dtype
         return hipErrorInvalidValue;
     if (((uintptr_t)a.X | (uintptr_t)a.W | (uintptr_t)a.W2) & 15) return hipErrorInvalidValue;
     if (a.W2 && (a.N % epc_in)) return hipErrorInvalidValue;
-    if (in_dtype == Q3_F32 && out_dtype == Q3_F32) return launch_typed<float, float>(a, s);
-    if (in_dtype == Q3_BF16 && out_dtype == Q3_BF16) return launch_typed<bf16, bf16>(a, s);
-    if (a.W2) return hipErrorInvalidValue;
-    if (in_dtype == Q3_F32 && out_dtype == Q3_BF16) return launch_typed_nofuse<float, bf16>(a, s);
-    if (in_dtype == Q3_BF16 && out_dtype == Q3_F32) return launch_typed_nofuse<bf16, float>(a, s);
+    if (in_dtype == Q3_F32 && out_dtype == Q3_F32) return launch_typed<float, float, true>(a, s);
+    if (in_dtype == Q3_BF16 && out_dtype == Q3_BF16) return launch_typed<bf16, bf16, true>(a, s);
+    if (in_dtype == Q3_F32 && out_dtype == Q3_BF16) return launch_typed<float, bf16, false>(a, s);
+    if (in_dtype == Q3_BF16 && out_dtype == Q3_F32) return launch_typed<bf16, float, false>(a, s);
     return hipErrorInvalidValue;
 }

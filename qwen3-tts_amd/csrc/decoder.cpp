@@ -232,7 +232,6 @@ int pack_vec(q3c_ctx* c, const std::string& name, int n, float** out) {
 
 // ---- one convgemm launch --------------------------------------------------------------------------------
 struct GemmOpts {
-    const Snake* pro = nullptr;
     int act = Q3_ACT_NONE;
     const Snake* epi = nullptr;
     const float* scale = nullptr;
@@ -253,7 +252,6 @@ int gemm(q3c_ctx* c, const GemmW& g, const void* X, int B, int L_in, void* Y, in
     a.R = o.R; a.ldr = n_out; a.r_batch_stride = (long long)M * n_out;
     a.B = B; a.M = M; a.N = g.N; a.K = g.K;
     a.taps = g.taps; a.off0 = g.off0; a.off_step = g.off_step;
-    if (o.pro) { a.pro_a = o.pro->a; a.pro_invb = o.pro->invb; }
     a.act = o.act;
     if (o.epi) { a.epi_a = o.epi->a; a.epi_invb = o.epi->invb; }
     a.scale = o.scale;
@@ -268,7 +266,7 @@ int gemm(q3c_ctx* c, const GemmW& g, const void* X, int B, int L_in, void* Y, in
         pname = q3_convgemm_variant(a, g.in_dtype, out_dtype);
         if (c->profile_detail) {      // one entry per layer shape: interned so the pointer outlives this call
             char buf[64];
-            std::snprintf(buf, sizeof(buf), "%.24s M%dxN%dxK%dxT%d%s", pname + 9, a.B * a.M, a.N, a.K, a.taps, o.pro ? "+pro" : "");
+            std::snprintf(buf, sizeof(buf), "%.24s M%dxN%dxK%dxT%d%s", pname + 9, a.B * a.M, a.N, a.K, a.taps, o.second ? "+1x1" : "");
             pname = c->interned.insert(buf).first->c_str();
         }
     }
@@ -716,7 +714,7 @@ int q3c_forward(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, float* w
             TRY(gemm(c, b.tconv, cur, B, L, raw, Lq, dt, g, s));              // [B, L-1, r*ch] == [B, (L-1)*r, ch]
         }
         L = Lq * b.rate;
-        const bool fuse = c->fuse_units && q3_convgemm_fusable(ch);
+        const bool fuse = c->fuse_units && q3_convgemm_fusable(ch, dt);
         for (size_t j = 0; j < b.units.size(); ++j) {
             const Unit& u = b.units[j];
             const bool last = j + 1 == b.units.size();
