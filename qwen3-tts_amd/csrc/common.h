@@ -38,6 +38,7 @@ struct ConvGemmArgs {
     const float* post_a; const float* post_invb;         // [N_out] snake after the residual add, or null
     void* Y2;                                            // optional second output (same strides as Y)
     const void* W2; const float* bias2;                  // [N][N] second contraction, or null
+    const void* zeros;                                   // >= 16 bytes of zeros in device memory (source of out-of-sequence rows)
 };
 
 enum Q3Dtype : int { Q3_F32 = 0, Q3_BF16 = 1 };

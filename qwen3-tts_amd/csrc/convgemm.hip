@@ -66,6 +66,17 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // more than we count: drain
     }
 }
+// One LDS-DMA instruction: 16 bytes per lane from each lane's own global address to LDS at lds_addr + lane * 16
+// (lds_addr wave-uniform).  Issued through inline asm on purpose: the compiler then neither counts it nor guards later
+// ds_reads with vmcnt(0), so tiles can stay in flight across steps; completion is tracked by wait_vmcnt below.
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ unsigned lds_address(const void* generic_ptr_into_lds) {
+    return (unsigned)(unsigned long long)(lds_void*)generic_ptr_into_lds;
+}
 __device__ __forceinline__ void block_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -119,13 +130,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
     const int my_c = tid % CPR;                      // column chunk of every piece this thread stages
     const bool dma = (p.K % BK) == 0;                // whole chunks only: LDS-DMA cannot zero-fill a K tail
 
-    // buffer descriptor over the rows of X this tile may touch; anything else reads as zero
-    const int g0 = m0 + p.off0;
-    const int r_lo = g0 > 0 ? g0 : 0;
-    const int r_hi = (g0 + HR) < p.L_in ? (g0 + HR) : p.L_in;
-    const long long xrec = (long long)(r_hi > r_lo ? r_hi - r_lo : 0) * p.ldx * (int)sizeof(TA);
-    const __amdgpu_buffer_rsrc_t xrsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(Xb + (long long)r_lo * p.ldx), 0, (int)xrec, 0x00020000);
+    const int g0 = m0 + p.off0;                      // sequence row of staged row 0
 
     // ---- input tile, register path (K tail only) ----
     auto x_load = [&](int id, int kc) -> uint4 {
@@ -143,18 +148,6 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
             *(uint4*)(xs + (size_t)row * BKB + swz<CPR>(row, my_c) * 16) = v;
         }
     };
-    // ---- input tile, LDS-DMA: iteration `it` of wave w writes the 1 KiB at (it*NW + w) KiB of the buffer; returns the
-    //      number of DMA instructions this wave issued (wave-uniform) ----
-    auto x_dma_issue = [&](unsigned char* xs, int it, int kc) -> int {
-        if ((it * NW + wave) * 64 >= xpieces) return 0;          // this wave's 1 KiB lies past the tile
-        const int id = tid + it * NTHR;
-        const int row = id / CPR;
-        const int c = swz<CPR>(row, my_c);                       // slot my_c of this row must receive chunk c
-        long long off = ((long long)(g0 + row - r_lo) * p.ldx + kc * BK + c * EPC) * (int)sizeof(TA);
-        unsigned voff = (id < xpieces && off >= 0 && off < xrec) ? (unsigned)off : 0x7fffff00u;   // out of range -> zeros
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)(xs + (size_t)(it * NW + wave) * 1024), 16, voff, 0, 0, 0);
-        return 1;
-    };
     // ---- weight tile ----
     auto w_load = [&](const TA* W, int ldw, int id, int kc, int tap) -> uint4 {
         int row = id / CPR, c = id % CPR;
@@ -171,22 +164,42 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
             *(uint4*)(ws + (size_t)row * BKB + swz<CPR>(row, c) * 16) = v;
         }
     };
-    auto w_dma_issue = [&](unsigned char* ws, const TA* W, int ldw, int kc, int tap) -> int {
-        int issued = 0;
+    // ---- LDS-DMA staging.  LDS destinations are lane-linear (1 KiB per wave instruction), so the chunk XOR is applied
+    //      to the SOURCE address.  Every call issues a fixed number of DMA instructions per wave (waves with nothing to
+    //      fetch aim a padding DMA at a spare KiB) so that the vmcnt bookkeeping needs no per-wave counts.
+    const unsigned lds0 = lds_address(smem);
+    const unsigned xs_lds = lds0, ws_lds = lds0 + (unsigned)round_kb(region0);
+    const unsigned spare_lds = ws_lds + 3 * (unsigned)WBUF;
+    const unsigned char* zero_page = (const unsigned char*)p.zeros;
+    constexpr int XROWS_PER_IT = NTHR / CPR;                     // rows one iteration of all waves covers (a multiple of 16)
+    const int xrow0 = tid / CPR;
+    const TA* xsrc0 = Xb + (long long)(g0 + xrow0) * p.ldx + swz<CPR>(xrow0, my_c) * EPC;
+    // input rows [it*XROWS_PER_IT ...) of chunk kc -> buffer at xs; rows outside the sequence come from the zero page
+    auto x_dma_issue = [&](unsigned xs, int it, int kc) {
+        const int slot = it * NW + wave;
+        if (slot * 64 >= xpieces) { dma16(zero_page, spare_lds); return; }
+        const int grow = g0 + xrow0 + it * XROWS_PER_IT;
+        const TA* src = xsrc0 + ((long long)it * XROWS_PER_IT * p.ldx + kc * BK);
+        const bool ok = grow >= 0 && grow < p.L_in;
+        dma16(ok ? (const void*)src : (const void*)zero_page, xs + (unsigned)slot * 1024u);
+    };
+    const TA* wsrc0[WITER];
+    const TA* w2src0[WITER];
+#pragma unroll
+    for (int q = 0; q < WITER; ++q) {
+        const int id = (q * NW + wave) * 64 + lane;
+        const int row = id / CPR, cs = id % CPR;
+        int n = n0 + row;
+        n = n < p.N ? n : p.N - 1;                               // columns past N are never stored: any finite row will do
+        wsrc0[q] = Wg + (long long)n * p.K + swz<CPR>(row, cs) * EPC;
+        w2src0[q] = FUSE2 ? (const TA*)p.W2 + (long long)n * p.N + swz<CPR>(row, cs) * EPC : nullptr;
+    }
+    auto w_dma_issue = [&](unsigned ws, const TA* const* src0, long long elem_offset) {
 #pragma unroll
         for (int q = 0; q < WITER; ++q) {
-            if ((q * NW + wave) * 64 < WPIECES) {                // wave-uniform
-                const int id = (q * NW + wave) * 64 + lane;
-                const int row = id / CPR, cs = id % CPR;
-                const int c = swz<CPR>(row, cs);
-                int n = n0 + row;
-                n = n < p.N ? n : p.N - 1;                       // columns past N are never stored: any finite row will do
-                const TA* src = W + ((long long)tap * p.N + n) * ldw + kc * BK + c * EPC;
-                __builtin_amdgcn_global_load_lds((global_cvoid*)src, (lds_void*)(ws + (size_t)(q * NW + wave) * 1024), 16, 0, 0);
-                ++issued;
-            }
+            if ((q * NW + wave) * 64 < WPIECES) dma16(src0[q] + elem_offset, ws + (unsigned)(q * NW + wave) * 1024u);
+            else dma16(zero_page, spare_lds);
         }
-        return issued;
     };
 
     f32x16 acc[WM][WN];
@@ -226,36 +239,38 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
 
     if (dma) {
         // ---- LDS-DMA pipeline: weight tiles two steps ahead in three buffers, the next chunk's input tile in slices
-        //      spread over this chunk's steps.  Each wave counts its own DMA instructions and waits with vmcnt(n) for all
-        //      but those that may stay in flight; one raw barrier per step.
-        for (int it = 0; it < xi_total; ++it) x_dma_issue(Xs0, it, 0);
-        w_dma_issue(Ws0, Wg, p.K, 0, 0);
-        int ahead = 0;
-        if (nsteps > 1) ahead = w_dma_issue(Ws0 + WBUF, Wg, p.K, p.taps > 1 ? 0 : 1, p.taps > 1 ? 1 : 0);
-        wait_vmcnt(ahead);
+        //      spread over this chunk's steps; each step waits with vmcnt(n) for all but the DMAs that may stay in
+        //      flight, then one raw barrier.
+        const long long tap_stride = (long long)p.N * p.K;       // elements between taps of W
+        for (int it = 0; it < xi_total; ++it) x_dma_issue(xs_lds, it, 0);
+        w_dma_issue(ws_lds, wsrc0, 0);
+        if (nsteps > 1) {
+            w_dma_issue(ws_lds + (unsigned)WBUF, wsrc0, p.taps > 1 ? tap_stride : (long long)BK);
+            wait_vmcnt(WITER);
+        } else {
+            wait_vmcnt(0);
+        }
         block_barrier();
         int kc = 0, tap = 0, wb = 0;                             // wb: weight buffer of the current step
+        int ltap = p.taps > 2 ? 2 : (p.taps == 2 ? 0 : 0), lkc = p.taps > 2 ? 0 : (p.taps == 2 ? 1 : 2);   // position of step + 2
         for (int step = 0; step < nsteps; ++step) {
-            int ntap = tap + 1, nkc_ = kc;
-            if (ntap == p.taps) { ntap = 0; nkc_ = kc + 1; }
-            int ntap2 = ntap + 1, nkc2 = nkc_;
-            if (ntap2 == p.taps) { ntap2 = 0; nkc2 = nkc_ + 1; }
             const int wb1 = wb == 2 ? 0 : wb + 1, wb2 = wb1 == 2 ? 0 : wb1 + 1;
-            int nx = 0, nw = 0;
-            if (kc + 1 < nkc) {
-                unsigned char* xsn = Xs0 + (size_t)((kc + 1) & 1) * XBUF;
+            const bool more_x = (kc + 1) < nkc, more_w = (step + 2) < nsteps;
+            if (more_x) {
+                const unsigned xsn = xs_lds + (unsigned)(((kc + 1) & 1) * XBUF);
 #pragma unroll
-                for (int i = 0; i < MAX_XPS; ++i) {
-                    int it = tap * xps + i;
-                    if (i < xps && it < xi_total) nx += x_dma_issue(xsn, it, kc + 1);
-                }
+                for (int i = 0; i < MAX_XPS; ++i)
+                    if (i < xps) x_dma_issue(xsn, tap * xps + i, kc + 1);
             }
-            if (step + 2 < nsteps) nw = w_dma_issue(Ws0 + (size_t)wb2 * WBUF, Wg, p.K, nkc2, ntap2);
+            if (more_w) w_dma_issue(ws_lds + (unsigned)(wb2 * WBUF), wsrc0, ltap * tap_stride + (long long)lkc * BK);
             compute(Xs0 + (size_t)(kc & 1) * XBUF, Ws0 + (size_t)wb * WBUF, tap * p.off_step);
-            // next step needs weight tile step+1 (issued one step ago) and, when it opens a new chunk, every input slice
-            wait_vmcnt(ntap == 0 ? nw : nx + nw);
+            // the next step needs weight tile step+1 (issued a step ago) and, when it opens a new chunk, every input slice
+            const bool boundary = (tap + 1) == p.taps;
+            wait_vmcnt((more_w ? WITER : 0) + ((more_x && !boundary) ? xps : 0));
             block_barrier();
-            tap = ntap; kc = nkc_; wb = wb1;
+            if (++tap == p.taps) { tap = 0; ++kc; }
+            if (++ltap == p.taps) { ltap = 0; ++lkc; }
+            wb = wb1;
         }
     } else {
         // ---- K tail (narrow test shapes): synchronous register staging, zero-filled past K ----
@@ -281,7 +296,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
         const TA* __restrict__ W2 = (const TA*)p.W2;
         const bool w2_dma = (p.N % BK) == 0;      // the h tile is consumed in whole chunks too
         // first W2 tile in flight while h is produced
-        if (w2_dma) w_dma_issue(Ws0, W2, p.N, 0, 0);
+        if (w2_dma) w_dma_issue(ws_lds, w2src0, 0);
         else {
 #pragma unroll
             for (int it = 0; it < WITER; ++it) w_store(Ws0, tid + it * NTHR, w_load(W2, p.N, tid + it * NTHR, 0, 0));
@@ -312,7 +327,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
             unsigned char* wsn = Ws0 + (size_t)((s2 + 1) & 1) * WBUF;
             uint4 wreg[WITER];
             if (has_next) {
-                if (w2_dma) w_dma_issue(wsn, W2, p.N, s2 + 1, 0);
+                if (w2_dma) w_dma_issue(ws_lds + (unsigned)(((s2 + 1) & 1) * WBUF), w2src0, (long long)(s2 + 1) * BK);
                 else {
 #pragma unroll
                     for (int it = 0; it < WITER; ++it) wreg[it] = w_load(W2, p.N, tid + it * NTHR, s2 + 1, 0);
@@ -487,7 +502,7 @@ hipError_t launch_cfg(const ConvGemmArgs& a, hipStream_t s) {
     if (FUSE2 && (a.N > BN || !a.W2 || a.act == Q3_ACT_SWIGLU)) return hipErrorInvalidValue;
     size_t region0 = 2 * round_kb((size_t)HR * BKB);
     if (FUSE2) region0 = std::max(region0, (size_t)BM * (a.N * sizeof(TA) + 16));
-    size_t lds = round_kb(region0) + 3 * round_kb((size_t)BN * BKB);
+    size_t lds = round_kb(region0) + 3 * round_kb((size_t)BN * BKB) + 1024;       // + a spare KiB for padding DMAs
     lds = std::max(lds, (size_t)NW * 32 * (32 * JG + 4) * sizeof(float));    // wave-private epilogue slabs
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     auto kern = convgemm_kernel<TA, TO, WAVES_M, WAVES_N, WM, WN, BKB, FUSE2>;

@@ -66,6 +66,7 @@ struct q3c_ctx {
     GemmW conv_out;
 
     int* err_flag = nullptr;
+    void* zero_page = nullptr;        // 256 zero bytes: what the kernels read for rows outside a sequence
     std::map<int, std::pair<float*, size_t>> taps;
 
     // per-kernel timing
@@ -230,6 +231,14 @@ int pack_vec(q3c_ctx* c, const std::string& name, int n, float** out) {
     return upload_f32(c, v->data, out);
 }
 
+int ensure_zero_page(q3c_ctx* c) {
+    if (c->zero_page) return 0;
+    int rc = dev_alloc(c, 256, &c->zero_page);
+    if (rc) return rc;
+    HIPCHK(c, hipMemset(c->zero_page, 0, 256));
+    return 0;
+}
+
 // ---- one convgemm launch --------------------------------------------------------------------------------
 struct GemmOpts {
     int act = Q3_ACT_NONE;
@@ -257,6 +266,7 @@ int gemm(q3c_ctx* c, const GemmW& g, const void* X, int B, int L_in, void* Y, in
     a.scale = o.scale;
     if (o.post) { a.post_a = o.post->a; a.post_invb = o.post->invb; }
     a.Y2 = o.Y2;
+    a.zeros = c->zero_page;
     if (o.second) { a.W2 = o.second->w; a.bias2 = o.second->bias; }
     if (g.taps == 1 && M == L_in) {      // no halo: batch items are just more rows
         a.M = B * M; a.L_in = B * L_in; a.B = 1;
@@ -426,6 +436,7 @@ int q3c_finalize(q3c_ctx* c) {
     TRY(dev_alloc(c, 16, &p));
     c->err_flag = (int*)p;
     HIPCHK(c, hipMemset(c->err_flag, 0, 16));
+    TRY(ensure_zero_page(c));
 
     const int H = k.hidden_size, Lt = k.latent_dim;
     // ---- front end ----
@@ -777,6 +788,7 @@ int q3c_profile_read(q3c_ctx* c, q3c_profile_entry* out, int32_t cap, int32_t* c
 static int op_run(GemmW& g, q3c_ctx* c, const float* x, int B, int L_in, int cin, float* y, int M, int n_out, int precision,
                   hipStream_t s) {
     const int dt = precision == Q3C_PRECISION_BF16 ? Q3_BF16 : Q3_F32;
+    TRY(ensure_zero_page(c));
     void *xi = nullptr, *yo = nullptr;
     int rc = 0;
     if (dt == Q3_BF16) {
