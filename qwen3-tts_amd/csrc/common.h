@@ -38,6 +38,7 @@ struct ConvGemmArgs {
     const float* post_a; const float* post_invb;         // [N_out] snake after the residual add, or null
     void* Y2;                                            // optional second output (same strides as Y)
     const void* W2; const float* bias2;                  // [N][N] second contraction, or null
+    int debug;                                           // measurement aid: bit 0 skip epilogue memory, 1 skip MFMAs, 2 skip fused 1x1, 3 skip epilogue math
     const void* zeros;                                   // >= 16 bytes of zeros in device memory (source of out-of-sequence rows)
 };
 
@@ -99,7 +100,9 @@ __device__ __forceinline__ float q3_sin_f32(float x) {
 }
 template <typename T> __device__ __forceinline__ float q3_sin(float x);
 template <> __device__ __forceinline__ float q3_sin<float>(float x) { return q3_sin_f32(x); }
-template <> __device__ __forceinline__ float q3_sin<bf16>(float x) { return __sinf(x); }
+// bf16 path: the hardware sine takes its argument in REVOLUTIONS; the host folds 1/(2 pi) into the per-channel
+// frequency it uploads for bf16 contexts, so q3_snake<bf16> is mul, v_sin, mul, fma.
+template <> __device__ __forceinline__ float q3_sin<bf16>(float x) { return __builtin_amdgcn_sinf(x); }
 
 template <typename T> __device__ __forceinline__ float q3_snake(float x, float a, float invb) {
     float s = q3_sin<T>(x * a);

@@ -57,22 +57,27 @@ template <> struct Mma<float> {
 __host__ __device__ constexpr size_t round_kb(size_t v) { return (v + 1023) / 1024 * 1024; }
 
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n: all but the n youngest vector-memory operations are done.
+// n above 7 drains instead (always safe: it only waits longer).
 __device__ __forceinline__ void wait_vmcnt(int n) {
-    switch (n) {
-#define Q3_VM(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-        Q3_VM(0) Q3_VM(1) Q3_VM(2) Q3_VM(3) Q3_VM(4) Q3_VM(5) Q3_VM(6) Q3_VM(7) Q3_VM(8) Q3_VM(9) Q3_VM(10) Q3_VM(11)
-        Q3_VM(12) Q3_VM(13) Q3_VM(14) Q3_VM(15) Q3_VM(16) Q3_VM(17) Q3_VM(18) Q3_VM(19) Q3_VM(20) Q3_VM(21) Q3_VM(22) Q3_VM(23)
-#undef Q3_VM
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // more than we count: drain
+    if (n >= 4) {
+        if (n >= 6) { if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else if (n == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        else { if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
+    } else {
+        if (n >= 2) { if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
+        else { if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     }
 }
-// One LDS-DMA instruction: 16 bytes per lane from each lane's own global address to LDS at lds_addr + lane * 16
-// (lds_addr wave-uniform).  Issued through inline asm on purpose: the compiler then neither counts it nor guards later
-// ds_reads with vmcnt(0), so tiles can stay in flight across steps; completion is tracked by wait_vmcnt below.
+// One LDS-DMA instruction: 16 bytes per lane from global memory to LDS at lds_addr + lane * 16 (lds_addr wave-uniform).
+// Issued through inline asm on purpose: the compiler then neither counts it nor guards later ds_reads with vmcnt(0), so
+// tiles can stay in flight across steps; completion is tracked by wait_vmcnt below.  M0 (the LDS base of an LDS-DMA) is
+// written in the same statement; nothing else in these kernels uses M0.
+//   dma16    : every lane supplies a full 64-bit address
+//   dma16_so : wave-uniform 64-bit base (SGPR pair) + unsigned 32-bit per-lane byte offset
 __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_addr) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void dma16_so(const void* sbase, unsigned voff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
 }
 __device__ __forceinline__ unsigned lds_address(const void* generic_ptr_into_lds) {
     return (unsigned)(unsigned long long)(lds_void*)generic_ptr_into_lds;
@@ -94,7 +99,6 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
     constexpr int KG = BKB / 32;                     // fragment groups per step
     constexpr int WPIECES = BN * CPR;
     constexpr int WITER = (WPIECES + NTHR - 1) / NTHR;
-    constexpr int MAX_XPS = (BM * CPR + NTHR - 1) / NTHR;
     constexpr size_t WBUF = round_kb((size_t)BN * BKB);
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per block");
     static_assert(NTHR % CPR == 0, "column chunk of a thread is fixed");
@@ -173,32 +177,39 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
     const unsigned char* zero_page = (const unsigned char*)p.zeros;
     constexpr int XROWS_PER_IT = NTHR / CPR;                     // rows one iteration of all waves covers (a multiple of 16)
     const int xrow0 = tid / CPR;
-    const TA* xsrc0 = Xb + (long long)(g0 + xrow0) * p.ldx + swz<CPR>(xrow0, my_c) * EPC;
+    // a tile whose staged rows (padding lanes included) all lie inside the sequence needs no per-lane checks
+    const bool interior = g0 >= 0 && (g0 + xi_total * XROWS_PER_IT) <= p.L_in;
+    const TA* xtile = Xb + (long long)g0 * p.ldx;                                      // wave-uniform
+    const unsigned xvoff0 = (unsigned)((xrow0 * p.ldx + swz<CPR>(xrow0, my_c) * EPC) * (int)sizeof(TA));
     // input rows [it*XROWS_PER_IT ...) of chunk kc -> buffer at xs; rows outside the sequence come from the zero page
     auto x_dma_issue = [&](unsigned xs, int it, int kc) {
         const int slot = it * NW + wave;
-        if (slot * 64 >= xpieces) { dma16(zero_page, spare_lds); return; }
-        const int grow = g0 + xrow0 + it * XROWS_PER_IT;
-        const TA* src = xsrc0 + ((long long)it * XROWS_PER_IT * p.ldx + kc * BK);
-        const bool ok = grow >= 0 && grow < p.L_in;
-        dma16(ok ? (const void*)src : (const void*)zero_page, xs + (unsigned)slot * 1024u);
+        if (slot * 64 >= xpieces) { dma16_so(zero_page, 0u, spare_lds); return; }
+        const TA* sbase = xtile + ((long long)it * XROWS_PER_IT * p.ldx + kc * BK);
+        if (interior) {
+            dma16_so(sbase, xvoff0, xs + (unsigned)slot * 1024u);
+        } else {
+            const int grow = g0 + xrow0 + it * XROWS_PER_IT;
+            const unsigned long long real = (unsigned long long)sbase + xvoff0;
+            const unsigned long long src = (grow >= 0 && grow < p.L_in) ? real : (unsigned long long)zero_page;
+            dma16((const void*)src, xs + (unsigned)slot * 1024u);
+        }
     };
-    const TA* wsrc0[WITER];
-    const TA* w2src0[WITER];
+    unsigned wvoff[WITER], w2voff[WITER];
 #pragma unroll
     for (int q = 0; q < WITER; ++q) {
         const int id = (q * NW + wave) * 64 + lane;
         const int row = id / CPR, cs = id % CPR;
         int n = n0 + row;
         n = n < p.N ? n : p.N - 1;                               // columns past N are never stored: any finite row will do
-        wsrc0[q] = Wg + (long long)n * p.K + swz<CPR>(row, cs) * EPC;
-        w2src0[q] = FUSE2 ? (const TA*)p.W2 + (long long)n * p.N + swz<CPR>(row, cs) * EPC : nullptr;
+        wvoff[q] = (unsigned)((n * p.K + swz<CPR>(row, cs) * EPC) * (int)sizeof(TA));
+        w2voff[q] = (unsigned)((n * p.N + swz<CPR>(row, cs) * EPC) * (int)sizeof(TA));
     }
-    auto w_dma_issue = [&](unsigned ws, const TA* const* src0, long long elem_offset) {
+    auto w_dma_issue = [&](unsigned ws, const TA* sbase, const unsigned* voff) {
 #pragma unroll
         for (int q = 0; q < WITER; ++q) {
-            if ((q * NW + wave) * 64 < WPIECES) dma16(src0[q] + elem_offset, ws + (unsigned)(q * NW + wave) * 1024u);
-            else dma16(zero_page, spare_lds);
+            if ((q * NW + wave) * 64 < WPIECES) dma16_so(sbase, voff[q], ws + (unsigned)(q * NW + wave) * 1024u);
+            else dma16_so(zero_page, 0u, spare_lds);
         }
     };
 
@@ -243,27 +254,26 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
         //      flight, then one raw barrier.
         const long long tap_stride = (long long)p.N * p.K;       // elements between taps of W
         for (int it = 0; it < xi_total; ++it) x_dma_issue(xs_lds, it, 0);
-        w_dma_issue(ws_lds, wsrc0, 0);
+        w_dma_issue(ws_lds, Wg, wvoff);
         if (nsteps > 1) {
-            w_dma_issue(ws_lds + (unsigned)WBUF, wsrc0, p.taps > 1 ? tap_stride : (long long)BK);
+            w_dma_issue(ws_lds + (unsigned)WBUF, Wg + (p.taps > 1 ? tap_stride : (long long)BK), wvoff);
             wait_vmcnt(WITER);
         } else {
             wait_vmcnt(0);
         }
         block_barrier();
         int kc = 0, tap = 0, wb = 0;                             // wb: weight buffer of the current step
-        int ltap = p.taps > 2 ? 2 : (p.taps == 2 ? 0 : 0), lkc = p.taps > 2 ? 0 : (p.taps == 2 ? 1 : 2);   // position of step + 2
+        int ltap = p.taps > 2 ? 2 : 0, lkc = p.taps > 2 ? 0 : (p.taps == 2 ? 1 : 2);   // (tap, chunk) of step + 2
         for (int step = 0; step < nsteps; ++step) {
             const int wb1 = wb == 2 ? 0 : wb + 1, wb2 = wb1 == 2 ? 0 : wb1 + 1;
             const bool more_x = (kc + 1) < nkc, more_w = (step + 2) < nsteps;
             if (more_x) {
                 const unsigned xsn = xs_lds + (unsigned)(((kc + 1) & 1) * XBUF);
-#pragma unroll
-                for (int i = 0; i < MAX_XPS; ++i)
-                    if (i < xps) x_dma_issue(xsn, tap * xps + i, kc + 1);
+#pragma unroll 1
+                for (int i = 0; i < xps; ++i) x_dma_issue(xsn, tap * xps + i, kc + 1);
             }
-            if (more_w) w_dma_issue(ws_lds + (unsigned)(wb2 * WBUF), wsrc0, ltap * tap_stride + (long long)lkc * BK);
-            compute(Xs0 + (size_t)(kc & 1) * XBUF, Ws0 + (size_t)wb * WBUF, tap * p.off_step);
+            if (more_w) w_dma_issue(ws_lds + (unsigned)(wb2 * WBUF), Wg + (ltap * tap_stride + (long long)lkc * BK), wvoff);
+            if (!(p.debug & 2)) compute(Xs0 + (size_t)(kc & 1) * XBUF, Ws0 + (size_t)wb * WBUF, tap * p.off_step);
             // the next step needs weight tile step+1 (issued a step ago) and, when it opens a new chunk, every input slice
             const bool boundary = (tap + 1) == p.taps;
             wait_vmcnt((more_w ? WITER : 0) + ((more_x && !boundary) ? xps : 0));
@@ -290,13 +300,13 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
     const int half = lane >> 5, l31 = lane & 31;
 
     // ---- fused second contraction (k = 1): h = snake(acc + bias) -> LDS -> acc = h . W2^T -------------------------
-    if constexpr (FUSE2) {
+    if (FUSE2 && !(p.debug & 4)) {
         const int HLD = p.N * (int)sizeof(TA) + 16;                 // padded row stride of the h tile
         unsigned char* Hs = smem;                                   // overlays the (now idle) input buffers
         const TA* __restrict__ W2 = (const TA*)p.W2;
         const bool w2_dma = (p.N % BK) == 0;      // the h tile is consumed in whole chunks too
         // first W2 tile in flight while h is produced
-        if (w2_dma) w_dma_issue(ws_lds, w2src0, 0);
+        if (w2_dma) w_dma_issue(ws_lds, W2, w2voff);
         else {
 #pragma unroll
             for (int it = 0; it < WITER; ++it) w_store(Ws0, tid + it * NTHR, w_load(W2, p.N, tid + it * NTHR, 0, 0));
@@ -327,7 +337,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
             unsigned char* wsn = Ws0 + (size_t)((s2 + 1) & 1) * WBUF;
             uint4 wreg[WITER];
             if (has_next) {
-                if (w2_dma) w_dma_issue(ws_lds + (unsigned)(((s2 + 1) & 1) * WBUF), w2src0, (long long)(s2 + 1) * BK);
+                if (w2_dma) w_dma_issue(ws_lds + (unsigned)(((s2 + 1) & 1) * WBUF), W2 + (long long)(s2 + 1) * BK, w2voff);
                 else {
 #pragma unroll
                     for (int it = 0; it < WITER; ++it) wreg[it] = w_load(W2, p.N, tid + it * NTHR, s2 + 1, 0);
@@ -366,9 +376,12 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
     }
 
     // ---- epilogue -----------------------------------------------------------------------------------
-    // The accumulator layout gives each lane ONE column of 16 rows.  Each wave passes its tile through a private
-    // fp32 LDS slab, 32 rows x <= 96 columns at a time, so that the global side is 16 contiguous bytes per lane:
-    // a row of the tile is stored (and its residual loaded) as whole 16-byte pieces by consecutive lanes.
+    // The accumulator layout gives each lane ONE column of 16 rows, while memory wants 16 contiguous bytes per lane.
+    // Each wave therefore passes its tile through private fp32 LDS slabs, 16 rows x <= 96 columns at a time:
+    //   phase 0  residual rows -> slab A            (row-wise, 16-byte loads)
+    //   phase 1  accumulator + bias, activation, scale, + slab A  -> slab A (raw), snake of the consumer -> slab B
+    //            (column-wise: the per-channel parameters are two registers per lane)
+    //   phase 2  slab A -> Y, slab B -> Y2           (row-wise, 16-byte stores)
     TO* __restrict__ Yb = (TO*)p.Y + (long long)b * p.y_batch_stride;
     TO* __restrict__ Y2b = p.Y2 ? (TO*)p.Y2 + (long long)b * p.y_batch_stride : nullptr;
     const TO* __restrict__ Rb = p.R ? (const TO*)p.R + (long long)b * p.r_batch_stride : nullptr;
@@ -376,8 +389,10 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
     constexpr int JG = WN < 3 ? WN : 3;                   // column tiles per slab pass
     constexpr int SCOLS = 32 * JG;
     constexpr int SLD = SCOLS + 4;                        // slab row stride in floats (keeps rows 16-byte aligned)
+    constexpr int SROWS = 16;
     static_assert(WN % JG == 0, "slab passes must tile the wave's columns");
-    float* slab = (float*)smem + wave * (32 * SLD);
+    float* slabA = (float*)smem + wave * (2 * SROWS * SLD);
+    float* slabB = slabA + SROWS * SLD;
     const bool swiglu = p.act == Q3_ACT_SWIGLU;
     const int n_out = swiglu ? p.N / 2 : p.N;
     const bool has_post = p.post_a != nullptr;
@@ -389,98 +404,121 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
     for (int i = 0; i < WM; ++i) {
 #pragma unroll
         for (int jg = 0; jg < WN; jg += JG) {
-            // phase 1: column-wise math, accumulators -> slab
-            int pcols, ncol0;                              // output columns of this pass and the first one's index
-            if (swiglu) {
-                pcols = SCOLS / 2;
-                ncol0 = (n0 >> 1) + wn * (16 * WN) + (jg >> 1) * 32;
-                if constexpr (JG % 2 == 0) {
+            const int pcols = swiglu ? SCOLS / 2 : SCOLS;              // output columns of this pass
+            const int ncol0 = swiglu ? ((n0 >> 1) + wn * (16 * WN) + (jg >> 1) * 32) : (n0 + wn * 32 * WN + jg * 32);
+            const int cprw = pcols / EPO;                               // 16-byte pieces per slab row
 #pragma unroll
-                    for (int j = 0; j < JG; j += 2) {
-                        const int cl = (j >> 1) * 32 + l31;
-                        const int n = ncol0 + cl;
-                        const float sc = (p.scale && n < n_out) ? p.scale[n] : 1.f;
+            for (int rh = 0; rh < 2; ++rh) {                            // rows 0-15, then 16-31 of the 32-row tile
+                const int mrow0 = m0 + wm * 32 * WM + i * 32 + rh * 16;
+                // phase 0: residual -> slab A
+                if (Rb && !(p.debug & 1)) {
+                    for (int id = lane; id < SROWS * cprw; id += 64) {
+                        const int row = id / cprw, ch = id - row * cprw;
+                        const int m = mrow0 + row, n = ncol0 + ch * EPO;
+                        float v[EPO];
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                            slab[row * SLD + cl] = q3_silu(acc[i][jg + j][r]) * acc[i][jg + j + 1][r] * sc;
+                        for (int e = 0; e < EPO; ++e) v[e] = 0.f;
+                        if (m < p.M && n < n_out) {
+                            if (vec_ok) {
+                                const uint4 raw = *(const uint4*)(Rb + (long long)m * p.ldr + n);
+                                const TO* rr = (const TO*)&raw;
+#pragma unroll
+                                for (int e = 0; e < EPO; ++e) v[e] = q3_to_f32(rr[e]);
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < EPO; ++e)
+                                    if (n + e < n_out) v[e] = q3_to_f32(Rb[(long long)m * p.ldr + n + e]);
+                            }
+                        }
+                        float* sp = slabA + row * SLD + ch * EPO;
+#pragma unroll
+                        for (int e = 0; e < EPO; e += 4) *(float4*)(sp + e) = make_float4(v[e], v[e + 1], v[e + 2], v[e + 3]);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                // phase 1: column-wise math
+                if (p.debug & 8) {
+                } else if (swiglu) {
+                    if constexpr (JG % 2 == 0) {
+#pragma unroll
+                        for (int j = 0; j < JG; j += 2) {
+                            const int cl = (j >> 1) * 32 + l31;
+                            const int n = ncol0 + cl;
+                            const float sc = (p.scale && n < n_out) ? p.scale[n] : 1.f;
+#pragma unroll
+                            for (int r8 = 0; r8 < 8; ++r8) {
+                                const int r = rh * 8 + r8;
+                                const int row = (r8 & 3) + 8 * (r8 >> 2) + 4 * half;
+                                float v = q3_silu(acc[i][jg + j][r]) * acc[i][jg + j + 1][r] * sc;
+                                if (Rb) v += slabA[row * SLD + cl];
+                                slabA[row * SLD + cl] = v;
+                            }
                         }
                     }
-                }
-            } else {
-                pcols = SCOLS;
-                ncol0 = n0 + wn * 32 * WN + jg * 32;
-#pragma unroll
-                for (int j = 0; j < JG; ++j) {
-                    const int cl = j * 32 + l31;
-                    const int n = ncol0 + cl;
-                    const bool nv = n < n_out;
-                    const float bias = (obias && nv) ? obias[n] : 0.f;
-                    const float sc = (p.scale && nv && !FUSE2) ? p.scale[n] : 1.f;
-                    float ea = 0.f, eib = 0.f;
-                    if (first_act == Q3_ACT_SNAKE && nv) { ea = p.epi_a[n]; eib = p.epi_invb[n]; }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                        float v = acc[i][jg + j][r] + bias;
-                        if (first_act == Q3_ACT_GELU) v = q3_gelu(v);
-                        else if (first_act == Q3_ACT_SNAKE) v = q3_snake<TO>(v, ea, eib);
-                        else if (first_act == Q3_ACT_CLAMP) v = fminf(1.0f, fmaxf(-1.0f, v));
-                        slab[row * SLD + cl] = v * sc;
-                    }
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            // phase 2: row-wise, 16 bytes per lane: + residual, snake of the consumer, store
-            const int cprw = pcols / EPO;                  // 16-byte pieces per slab row
-            const int mrow0 = m0 + wm * 32 * WM + i * 32;
-            for (int id = lane; id < 32 * cprw; id += 64) {
-                const int row = id / cprw, ch = id - row * cprw;
-                const int m = mrow0 + row, n = ncol0 + ch * EPO;
-                if (m >= p.M || n >= n_out) continue;
-                float v[EPO];
-                const float* sp = slab + row * SLD + ch * EPO;
-#pragma unroll
-                for (int e = 0; e < EPO; e += 4) {
-                    const float4 t4 = *(const float4*)(sp + e);
-                    v[e] = t4.x; v[e + 1] = t4.y; v[e + 2] = t4.z; v[e + 3] = t4.w;
-                }
-                const long long yo = (long long)m * p.ldy + n;
-                if (vec_ok) {
-                    if (Rb) {
-                        const uint4 raw = *(const uint4*)(Rb + (long long)m * p.ldr + n);
-                        const TO* rr = (const TO*)&raw;
-#pragma unroll
-                        for (int e = 0; e < EPO; ++e) v[e] += q3_to_f32(rr[e]);
-                    }
-                    uint4 outv;
-                    TO* oo = (TO*)&outv;
-                    if (Y2b) {
-#pragma unroll
-                        for (int e = 0; e < EPO; ++e) oo[e] = q3_from_f32<TO>(v[e]);
-                        *(uint4*)(Yb + yo) = outv;
-                    }
-                    if (has_post) {
-#pragma unroll
-                        for (int e = 0; e < EPO; ++e) v[e] = q3_snake<TO>(v[e], p.post_a[n + e], p.post_invb[n + e]);
-                    }
-#pragma unroll
-                    for (int e = 0; e < EPO; ++e) oo[e] = q3_from_f32<TO>(v[e]);
-                    *(uint4*)((Y2b ? Y2b : Yb) + yo) = outv;
                 } else {
 #pragma unroll
-                    for (int e = 0; e < EPO; ++e) {
-                        if (n + e < n_out) {
-                            float x = v[e];
-                            if (Rb) x += q3_to_f32(Rb[(long long)m * p.ldr + n + e]);
-                            if (Y2b) Yb[yo + e] = q3_from_f32<TO>(x);
-                            if (has_post) x = q3_snake<TO>(x, p.post_a[n + e], p.post_invb[n + e]);
-                            (Y2b ? Y2b : Yb)[yo + e] = q3_from_f32<TO>(x);
+                    for (int j = 0; j < JG; ++j) {
+                        const int cl = j * 32 + l31;
+                        const int n = ncol0 + cl;
+                        const bool nv = n < n_out;
+                        const float bias = (obias && nv) ? obias[n] : 0.f;
+                        const float sc = (p.scale && nv && !FUSE2) ? p.scale[n] : 1.f;
+                        float ea = 0.f, eib = 0.f, qa = 0.f, qib = 0.f;
+                        if (first_act == Q3_ACT_SNAKE && nv) { ea = p.epi_a[n]; eib = p.epi_invb[n]; }
+                        if (has_post && nv) { qa = p.post_a[n]; qib = p.post_invb[n]; }
+#pragma unroll
+                        for (int r8 = 0; r8 < 8; ++r8) {
+                            const int r = rh * 8 + r8;
+                            const int row = (r8 & 3) + 8 * (r8 >> 2) + 4 * half;
+                            float v = acc[i][jg + j][r] + bias;
+                            if (first_act == Q3_ACT_GELU) v = q3_gelu(v);
+                            else if (first_act == Q3_ACT_SNAKE) v = q3_snake<TO>(v, ea, eib);
+                            else if (first_act == Q3_ACT_CLAMP) v = fminf(1.0f, fmaxf(-1.0f, v));
+                            v *= sc;
+                            if (Rb) v += slabA[row * SLD + cl];
+                            if (Y2b) {
+                                slabA[row * SLD + cl] = v;
+                                slabB[row * SLD + cl] = q3_snake<TO>(v, qa, qib);
+                            } else {
+                                slabA[row * SLD + cl] = has_post ? q3_snake<TO>(v, qa, qib) : v;
+                            }
                         }
                     }
                 }
+                __builtin_amdgcn_wave_barrier();
+                // phase 2: slabs -> memory, 16 bytes per lane
+                if (!(p.debug & 1))
+                for (int id = lane; id < SROWS * cprw; id += 64) {
+                    const int row = id / cprw, ch = id - row * cprw;
+                    const int m = mrow0 + row, n = ncol0 + ch * EPO;
+                    if (m >= p.M || n >= n_out) continue;
+                    const long long yo = (long long)m * p.ldy + n;
+#pragma unroll
+                    for (int which = 0; which < 2; ++which) {
+                        if (which == 1 && !Y2b) break;
+                        const float* sp = (which ? slabB : slabA) + row * SLD + ch * EPO;
+                        TO* dst = (which ? Y2b : Yb) + yo;
+                        float v[EPO];
+#pragma unroll
+                        for (int e = 0; e < EPO; e += 4) {
+                            const float4 t4 = *(const float4*)(sp + e);
+                            v[e] = t4.x; v[e + 1] = t4.y; v[e + 2] = t4.z; v[e + 3] = t4.w;
+                        }
+                        if (vec_ok) {
+                            uint4 outv;
+                            TO* oo = (TO*)&outv;
+#pragma unroll
+                            for (int e = 0; e < EPO; ++e) oo[e] = q3_from_f32<TO>(v[e]);
+                            *(uint4*)dst = outv;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < EPO; ++e)
+                                if (n + e < n_out) dst[e] = q3_from_f32<TO>(v[e]);
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -503,7 +541,7 @@ hipError_t launch_cfg(const ConvGemmArgs& a, hipStream_t s) {
     size_t region0 = 2 * round_kb((size_t)HR * BKB);
     if (FUSE2) region0 = std::max(region0, (size_t)BM * (a.N * sizeof(TA) + 16));
     size_t lds = round_kb(region0) + 3 * round_kb((size_t)BN * BKB) + 1024;       // + a spare KiB for padding DMAs
-    lds = std::max(lds, (size_t)NW * 32 * (32 * JG + 4) * sizeof(float));    // wave-private epilogue slabs
+    lds = std::max(lds, (size_t)NW * 2 * 16 * (32 * JG + 4) * sizeof(float));    // two wave-private 16-row epilogue slabs per wave
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     auto kern = convgemm_kernel<TA, TO, WAVES_M, WAVES_N, WM, WN, BKB, FUSE2>;
     if (lds > 48 * 1024) {
@@ -561,6 +599,7 @@ hipError_t launch_typed(const ConvGemmArgs& a, hipStream_t s) {
 // the h tile of the fused residual unit (256 rows x N channels of the operand type) must fit LDS beside the weight buffers
 int q3_convgemm_fusable(int N, int dtype) { return N <= (dtype == Q3_BF16 ? 192 : 96); }
 void q3_convgemm_set_tuning(int bits) { g_tuning = bits; }
+extern "C" void q3c_debug_set_tuning(int bits) { g_tuning = bits; }   // measurement aid (tools/): not part of include/q3c.h
 
 const char* q3_convgemm_variant(const ConvGemmArgs& a, int in_dtype, int out_dtype) {
     static const char* shapes[SH_COUNT] = {"256x96,k64B,4w", "256x128,k128B,8w", "128x128,k128B,4w", "128x128,k64B,4w", "256x32,k64B,4w",
@@ -574,7 +613,9 @@ const char* q3_convgemm_variant(const ConvGemmArgs& a, int in_dtype, int out_dty
     return names[t][sh];
 }
 
-hipError_t q3_launch_convgemm(const ConvGemmArgs& a, int in_dtype, int out_dtype, hipStream_t s) {
+hipError_t q3_launch_convgemm(const ConvGemmArgs& a_in, int in_dtype, int out_dtype, hipStream_t s) {
+    ConvGemmArgs a = a_in;
+    a.debug = g_tuning >> 8;
     if (a.M <= 0 || a.B <= 0) return hipSuccess;
     const int epc_in = in_dtype == Q3_BF16 ? 8 : 4;
     if (a.K % epc_in || a.ldx % epc_in || a.x_batch_stride % epc_in || a.taps < 1 || a.off_step < 0)

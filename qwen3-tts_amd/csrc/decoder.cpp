@@ -210,7 +210,9 @@ int pack_tconv(q3c_ctx* c, const std::string& prefix, int cin, int cout, int k, 
 }
 int pack_snake_host(q3c_ctx* c, const float* alpha, const float* beta, int C, float eps, Snake* s) {
     std::vector<float> va(C), vb(C);
-    for (int i = 0; i < C; ++i) { va[i] = expf(alpha[i]); vb[i] = 1.0f / (expf(beta[i]) + eps); }
+    // bf16 contexts evaluate the sine with v_sin_f32, whose argument is in revolutions: fold 1/(2 pi) into the frequency
+    const float fold = c->dtype == Q3_BF16 ? 0.15915494309189535f : 1.0f;
+    for (int i = 0; i < C; ++i) { va[i] = expf(alpha[i]) * fold; vb[i] = 1.0f / (expf(beta[i]) + eps); }
     s->C = C;
     int rc;
     if ((rc = upload_f32(c, va, &s->a))) return rc;
