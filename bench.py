@@ -33,6 +33,24 @@ from qwen3_tts_amd.decoder import Decoder  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X
 PEAK_HBM_GBS = 8000.0
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written by tools/pmc_traffic.py from rocprofv3 --pmc passes
+
+
+def pmc_traffic(variant: str):
+    """HBM bytes per launch of a contraction-kernel variant from the committed PMC passes (None if not collected)."""
+    m = __import__("re").match(r"convgemm<(\w+),(\w+),(resunit )?(\d+)x(\d+),k(\d+)B,(\d)w>", variant)
+    if not m or not os.path.exists(PMC_TRAFFIC):
+        return None
+    ta, to, fused, bm, bn, kb, nw = m.groups()
+    mang = {"f32": "f", "bf16": "DF16b"}
+    shapes = {("256", "96", "4"): (4, 1, 2, 3), ("256", "128", "8"): (4, 2, 2, 2), ("128", "128", "4"): (2, 2, 2, 2),
+              ("256", "32", "4"): (4, 1, 2, 1), ("256", "192", "8"): (8, 1, 1, 6)}
+    sh = shapes.get((bm, bn, nw))
+    if sh is None:
+        return None
+    key = f"{mang[ta]}{mang[to]}Li{sh[0]}ELi{sh[1]}ELi{sh[2]}ELi{sh[3]}ELi{kb}ELb{1 if fused else 0}E"
+    rec = json.load(open(PMC_TRAFFIC)).get("kernels", {}).get(key)
+    return None if rec is None else rec["hbm_bytes_per_launch"]
 
 
 def cpu_baseline(cfg, weights, batch: int, frames: int, threads: int) -> dict:
@@ -124,7 +142,9 @@ def main() -> None:
         if dom["flops"] > 0:
             achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(dom["kernel"]),
+                    "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]),
+                    "algorithmic_flops_per_launch": round(dom["flops"] / dom["launches"]),
                     "launches_per_step": dom["launches"] // args.steps,
                     "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
                     "share_of_gpu_time": round(dom["ms"] / total_ms, 3)}

@@ -282,7 +282,10 @@ int gemm(q3c_ctx* c, const GemmW& g, const void* X, int B, int L_in, void* Y, in
             pname = c->interned.insert(buf).first->c_str();
         }
     }
-    ProfScope ps(c, s, pname, 2.0 * a.B * a.M * (double)a.N * (a.K * a.taps + (o.second ? a.N : 0)), 0.0);
+    // algorithmic bytes: input, weights, and each output / residual tensor once
+    const double abytes = (double)B * L_in * g.K * esize(g.in_dtype) + (double)g.taps * g.N * g.K * esize(g.in_dtype) +
+                          (double)B * M * n_out * esize(out_dtype) * (1 + (o.Y2 ? 1 : 0) + (o.R ? 1 : 0));
+    ProfScope ps(c, s, pname, 2.0 * a.B * a.M * (double)a.N * (a.K * a.taps + (o.second ? a.N : 0)), abytes);
     hipError_t e = q3_launch_convgemm(a, g.in_dtype, out_dtype, s);
     if (e != hipSuccess) return fail(c, Q3C_ERR_HIP, std::string("convgemm launch: ") + hipGetErrorString(e));
     return 0;
