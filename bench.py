@@ -69,6 +69,54 @@ def cpu_baseline(cfg, weights, batch: int, frames: int, threads: int) -> dict:
                       f"restatement of the decode, 1 timed run, no warm-up ({dt:.1f} s)"}
 
 
+def stream_bench(args, cfg, weights, device) -> dict:
+    """BASELINE.json configs[2]: `--streams` concurrent streams, each advanced `--push-frames` frames (80 ms of audio
+    per frame) per step in ONE launch sequence, causal state carried in HBM; streams start at staggered positions.
+    Latency of a step = host wall time from submitting the push to its samples being complete on the device."""
+    import numpy as np
+    S, n = args.streams, args.push_frames
+    dec = Decoder(cfg, weights, device=device, precision=args.precision, max_positions=max(8192, (args.steps + args.warmup + 16) * n))
+    pool = dec.open_streams(S)
+    ids = pool.open_many(S)
+    ids_dev = torch.tensor(ids, dtype=torch.int32, device=device)
+    for j in range(1, 8):                                   # stagger: stream i starts (i % 8) frames ahead
+        sub = [i for i in ids if i % 8 >= j]
+        if sub:
+            pool.push_raw(torch.tensor(sub, dtype=torch.int32, device=device), q3.random_codes(cfg, len(sub), 1, seed=100 + j).to(device))
+    codes = [q3.random_codes(cfg, S, n, seed=2 + j).to(device) for j in range(8)]
+    out = torch.empty((S, n * cfg.total_upsample), dtype=torch.float32, device=device)
+    for j in range(args.warmup):
+        pool.push_raw(ids_dev, codes[j % 8], out)
+    torch.cuda.synchronize(device)
+    lat = []
+    t_all = time.perf_counter()
+    for j in range(args.steps):
+        t0 = time.perf_counter()
+        pool.push_raw(ids_dev, codes[j % 8], out)
+        torch.cuda.synchronize(device)
+        lat.append((time.perf_counter() - t0) * 1e3)
+    elapsed = time.perf_counter() - t_all
+    dec._check(dec._lib.q3c_check_errors(dec._ctx, dec._stream()))
+    assert bool(torch.isfinite(out).all())
+    lat = np.asarray(lat)
+    audio = S * n / cfg.frame_rate * args.steps
+    # one profiled step for the kernel breakdown
+    dec.profile(True)
+    pool.push_raw(ids_dev, codes[0], out)
+    torch.cuda.synchronize(device)
+    prof = sorted(dec.profile_read(), key=lambda p: -p["ms"])
+    dec.profile(False)
+    return {"metric": "audio-sec decoded/sec", "value": round(audio / elapsed, 1), "unit": "audio-sec/sec", "n_gpus": 1,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"streaming decode: {S} concurrent streams x {n} frame(s) ({n * 80} ms of audio) per step, causal "
+                                   f"state carried in HBM, staggered positions, flagship architecture, random-init weights",
+                       "p50_ms": round(float(np.percentile(lat, 50)), 3), "p99_ms": round(float(np.percentile(lat, 99)), 3),
+                       "max_ms": round(float(lat.max()), 3), "real_time_factor": round(n * 80.0 / float(np.percentile(lat, 99)), 1),
+                       "state_bytes_per_stream": pool.state_bytes_per_stream},
+            "kernels": [{"kernel": p["kernel"], "launches": p["launches"], "ms_per_step": round(p["ms"], 3)} for p in prof[:8]]}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,6 +129,9 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=3, help="utterances in the CPU baseline sample")
     ap.add_argument("--tiny", action="store_true", help="tiny architecture (plumbing check only; not a valid result)")
+    ap.add_argument("--workload", default="bulk", choices=["bulk", "stream"], help="bulk = configs[1] (the headline); stream = configs[2]")
+    ap.add_argument("--streams", type=int, default=256)
+    ap.add_argument("--push-frames", type=int, default=1)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -97,6 +148,11 @@ def main() -> None:
 
     cfg = q3.tiny_config() if args.tiny else q3.flagship_config()
     weights = q3.synthetic_weights(cfg, seed=0)
+    if args.workload == "stream":
+        if distributed:
+            raise SystemExit("the streaming workload is measured on one GPU (streams never migrate between GPUs)")
+        print(json.dumps(stream_bench(args, cfg, weights, device)), flush=True)
+        return
     frames = int(round(args.seconds * cfg.frame_rate))
     dec = Decoder(cfg, weights, device=device, precision=args.precision, max_frames_per_launch=args.batch * 325)
     codes = q3.random_codes(cfg, args.batch, frames, seed=1 + rank).to(device)

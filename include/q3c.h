@@ -101,12 +101,38 @@ int q3c_forward(q3c_ctx* ctx, const int64_t* codes_dev, int32_t batch, int32_t f
 int q3c_rvq_dequant_f32(q3c_ctx* ctx, const int64_t* codes_dev, int32_t batch, int32_t frames, float* sums_dev,
                         void* hip_stream);
 
-/* Sticky device-side error word (out-of-range code index).  Synchronises the stream; returns Q3C_ERR_CODES if set
- * and clears it.  Stands in for the IndexError torch's embedding raises. */
+/* Sticky device-side error word.  Synchronises the stream; if set, clears it and returns Q3C_ERR_CODES (a code index
+ * outside [0, codebook_size): stands in for the IndexError torch's embedding raises) or Q3C_ERR_INVALID_ARGUMENT
+ * (streaming: bad slot id, stream longer than max_positions). */
 int q3c_check_errors(q3c_ctx* ctx, void* hip_stream);
 
 /* Capture a stage output of the following q3c_forward calls as fp32 into caller memory (NULL removes the tap). */
 int q3c_set_tap(q3c_ctx* ctx, int32_t stage, float* dev_buffer, size_t capacity_elements);
+
+/* -- streaming decode ---------------------------------------------------------------------------------------
+ * The reference decodes whole utterances and sends one SSE `audio` event per request (server.py:245-251, 299-335);
+ * the sibling's only incremental form is chunked_decode, which recomputes 25 frames of context per chunk
+ * (sib :3686-3696).  Every layer of the decode is causal, so a stream can instead be advanced n frames at a time and
+ * produce exactly the samples of the un-chunked forward (sib :3672-3684) of all its frames so far: the rows each layer
+ * looks back into (conv taps - the causal padding of sib :3180-3213, the previous input row of the transposed convs
+ * :3216-3228, the 72-frame attention window :3267-3336, following the padding-cache pattern of mimi :73-164) are
+ * carried between pushes in a per-slot state record in device memory.
+ *
+ * A pool holds `capacity` slots.  q3c_stream_reset zeroes the given slots (a new stream starts at frame 0).
+ * q3c_stream_push advances S distinct slots (ids in DEVICE memory) by n frames each in one launch sequence, whatever
+ * their positions: codes [S][Q][n] int64 -> wav [S][n*total_upsample] fp32.  Over a stream's life the concatenated
+ * pushes are `trim` blank samples (zeros, at the start of its first push) followed by the un-chunked forward's output
+ * for the frames pushed so far.  Errors found on the device (slot id outside the pool, more than max_positions
+ * frames in one stream) are reported by q3c_check_errors.  The first push with a new (S, n) pair allocates a small
+ * descriptor table; later ones allocate nothing.  Destroy pools before their context. */
+typedef struct q3c_stream_pool q3c_stream_pool;
+int q3c_stream_pool_create(q3c_ctx* ctx, int32_t capacity, q3c_stream_pool** out);
+void q3c_stream_pool_destroy(q3c_stream_pool* pool);
+int q3c_stream_state_bytes(const q3c_stream_pool* pool, size_t* bytes_per_slot);
+int q3c_stream_reset(q3c_stream_pool* pool, const int32_t* slots_dev, int32_t count, void* hip_stream);
+int q3c_stream_workspace_bytes(q3c_stream_pool* pool, int32_t streams, int32_t frames, size_t* bytes);
+int q3c_stream_push(q3c_stream_pool* pool, const int32_t* slots_dev, int32_t streams, const int64_t* codes_dev, int32_t frames,
+                    float* wav_dev, void* workspace_dev, size_t workspace_bytes, void* hip_stream);
 
 /* -- per-kernel timing (no counterpart in the reference; used by bench.py for the roofline figures) -----------
  * While enabled, every kernel launch of q3c_forward is bracketed by a pair of HIP events on the caller's stream.

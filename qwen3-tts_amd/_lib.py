@@ -19,7 +19,8 @@ STAGE_RVQ_OUT, STAGE_TRANSFORMER_IN, STAGE_TRANSFORMER_OUT, STAGE_UPSAMPLE0, STA
 EXPORTS = ["q3c_create", "q3c_destroy", "q3c_last_error", "q3c_version", "q3c_load_weight", "q3c_finalize",
            "q3c_workspace_bytes", "q3c_output_length", "q3c_forward", "q3c_rvq_dequant_f32", "q3c_check_errors",
            "q3c_set_tap", "q3c_causal_conv1d", "q3c_causal_tconv1d", "q3c_snake_beta", "q3c_profile_enable",
-           "q3c_profile_read"]
+           "q3c_profile_read", "q3c_stream_pool_create", "q3c_stream_pool_destroy", "q3c_stream_state_bytes",
+           "q3c_stream_reset", "q3c_stream_workspace_bytes", "q3c_stream_push"]
 
 
 class Q3cProfileEntry(C.Structure):
@@ -83,9 +84,16 @@ def load() -> C.CDLL:
     lib.q3c_snake_beta.argtypes = [vp, C.c_int64, i32, vp, vp, C.c_float, vp, vp]
     lib.q3c_profile_enable.argtypes = [vp, i32]
     lib.q3c_profile_read.argtypes = [vp, C.POINTER(Q3cProfileEntry), i32, C.POINTER(i32)]
+    lib.q3c_stream_pool_create.argtypes = [vp, i32, C.POINTER(vp)]
+    lib.q3c_stream_pool_destroy.argtypes = [vp]
+    lib.q3c_stream_pool_destroy.restype = None
+    lib.q3c_stream_state_bytes.argtypes = [vp, C.POINTER(C.c_size_t)]
+    lib.q3c_stream_reset.argtypes = [vp, vp, i32, vp]
+    lib.q3c_stream_workspace_bytes.argtypes = [vp, i32, i32, C.POINTER(C.c_size_t)]
+    lib.q3c_stream_push.argtypes = [vp, vp, i32, vp, i32, vp, vp, C.c_size_t, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name not in ("q3c_destroy", "q3c_last_error", "q3c_version"):
+        if name not in ("q3c_destroy", "q3c_last_error", "q3c_version", "q3c_stream_pool_destroy"):
             fn.restype = C.c_int
     _lib = lib
     return lib

@@ -36,7 +36,11 @@ struct ConvGemmArgs {
     const float* epi_a; const float* epi_invb;           // [N] for Q3_ACT_SNAKE
     const float* scale;                                  // [N_out] or null
     const float* post_a; const float* post_invb;         // [N_out] snake after the residual add, or null
-    void* Y2;                                            // optional second output (same strides as Y)
+    void* Y2; long long y2_batch_stride;                 // optional second output (row stride ldy)
+    const int* row_start;                                // [B] or null: output rows below row_start[b] are stored as zeros
+    int seg_len, seg_hist;                               // > 0: B == 1 and the M rows are segments of seg_len rows whose first
+                                                         // seg_hist rows are carried context (read, never written); segment j,
+                                                         // row r >= seg_hist goes to batch item j, row r - seg_hist of Y / Y2 / R
     const void* W2; const float* bias2;                  // [N][N] second contraction, or null
     int debug;                                           // measurement aid: bit 0 skip epilogue memory, 1 skip MFMAs, 2 skip fused 1x1, 3 skip epilogue math
     const void* zeros;                                   // >= 16 bytes of zeros in device memory (source of out-of-sequence rows)
@@ -57,10 +61,29 @@ hipError_t q3_launch_rvq_gather_sum(const long long* codes, int B, int Q, int T,
 hipError_t q3_launch_mean_embedding(const long long* codes, int B, int Q, int T, int bins, int H,
                                     const float* table, void* out, int out_dtype, int* err_flag, hipStream_t s);
 hipError_t q3_launch_rmsnorm(const void* x, const float* w, void* y, long long rows, int H, float eps, int dtype, hipStream_t s);
+// `hist` carried rows sit in front of each item's L rows of x (0: rows before the sequence are zero padding)
 hipError_t q3_launch_dwconv_ln(const void* x, const float* w /*[C][7]*/, const float* b, const float* lnw, const float* lnb,
-                               void* y, int B, int L, int C, int k, float eps, int dtype, hipStream_t s);
+                               void* y, int B, int L, int C, int k, float eps, int dtype, hipStream_t s, int hist = 0);
+// qkv holds hist + T rows per item, the last T are the queries; pos0[b] (null: 0) is the frame number of query 0
 hipError_t q3_launch_swa_attention(const void* qkv, void* out, const float* cos_t, const float* sin_t, int B, int T,
-                                   int nh, int nkv, int d, int window, int dtype, hipStream_t s);
+                                   int nh, int nkv, int d, int window, int dtype, hipStream_t s, int hist = 0,
+                                   const int* pos0 = nullptr, int max_pos = 1 << 30);
+
+// one carried tensor of the streaming decode; offsets and strides in bytes, all multiples of 16
+struct Q3CarryDesc {
+    long long work_off, work_bstride;   // item b's [carried | new] rows start at work + work_off + b * work_bstride
+    long long state_off;                // offset of the carried rows inside a slot's state record
+    int work_ld, col_off, row_bytes;    // row stride of the work tensor; first byte and width of the carried columns
+    int rows, new_rows;                 // carried rows; rows appended by one push
+    int pad;
+};
+struct Q3StageStarts { int count; int rows[16]; };
+hipError_t q3_launch_stream_carry(const Q3CarryDesc* descs_dev, int ndesc, void* work, void* state, long long slot_stride,
+                                  const int* slots, int S, int capacity, int save, hipStream_t s);
+hipError_t q3_launch_stream_prep(const int* slots, int S, int capacity, int* pos, int n, int max_pos, int* pos0, int* row_start,
+                                 const Q3StageStarts& st, int* err_flag, hipStream_t s);
+hipError_t q3_launch_stream_reset(const int* slots, int count, int capacity, void* state, long long slot_stride, int* pos,
+                                  int* err_flag, hipStream_t s);
 hipError_t q3_launch_conv_out(const void* x, const float* w /*[k][C]*/, float bias, float* wav, int B, int L, int C, int k,
                               int dtype, hipStream_t s);
 hipError_t q3_launch_cast_to_f32(const void* x, float* y, long long n, int dtype, hipStream_t s);

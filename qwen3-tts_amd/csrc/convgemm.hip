@@ -88,7 +88,7 @@ __device__ __forceinline__ void block_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <typename TA, typename TO, int WAVES_M, int WAVES_N, int WM, int WN, int BKB, bool FUSE2>
+template <typename TA, typename TO, int WAVES_M, int WAVES_N, int WM, int WN, int BKB, bool FUSE2, bool SEG>
 __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const ConvGemmArgs p) {
     constexpr int NW = WAVES_M * WAVES_N;            // waves per block
     constexpr int NTHR = 64 * NW;
@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
     //            (column-wise: the per-channel parameters are two registers per lane)
     //   phase 2  slab A -> Y, slab B -> Y2           (row-wise, 16-byte stores)
     TO* __restrict__ Yb = (TO*)p.Y + (long long)b * p.y_batch_stride;
-    TO* __restrict__ Y2b = p.Y2 ? (TO*)p.Y2 + (long long)b * p.y_batch_stride : nullptr;
+    TO* __restrict__ Y2b = p.Y2 ? (TO*)p.Y2 + (long long)b * p.y2_batch_stride : nullptr;
     const TO* __restrict__ Rb = p.R ? (const TO*)p.R + (long long)b * p.r_batch_stride : nullptr;
     constexpr int EPO = 16 / (int)sizeof(TO);            // output elements per 16-byte piece
     constexpr int JG = WN < 3 ? WN : 3;                   // column tiles per slab pass
@@ -399,6 +399,15 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
     const bool vec_ok = (p.ldy % EPO == 0) && (!Rb || p.ldr % EPO == 0) && (n_out % EPO == 0);
     const int first_act = FUSE2 ? Q3_ACT_NONE : p.act;    // FUSE2 consumed the activation before its second contraction
     const float* obias = FUSE2 ? p.bias2 : p.bias;
+    // Segmented rows (streams stacked in one row space, each segment = carried rows + new rows): GEMM row m belongs
+    // to segment m / seg_len and is output row m % seg_len - seg_hist of it; carried rows produce no output.
+    // SEG instantiations serve the streaming decode only; the bulk path compiles to plain row addressing.
+    auto locate = [&](int m, int& bb, int& r) -> bool {
+        bb = 0; r = m;
+        if (m >= p.M) return false;
+        if constexpr (SEG) { bb = m / p.seg_len; r = m - bb * p.seg_len - p.seg_hist; }
+        return r >= 0;
+    };
 
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
@@ -418,16 +427,18 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
                         float v[EPO];
 #pragma unroll
                         for (int e = 0; e < EPO; ++e) v[e] = 0.f;
-                        if (m < p.M && n < n_out) {
+                        int bb, r;
+                        if (locate(m, bb, r) && n < n_out) {
+                            const TO* Rr = Rb + (SEG ? (long long)bb * p.r_batch_stride : 0LL) + (long long)r * p.ldr;
                             if (vec_ok) {
-                                const uint4 raw = *(const uint4*)(Rb + (long long)m * p.ldr + n);
+                                const uint4 raw = *(const uint4*)(Rr + n);
                                 const TO* rr = (const TO*)&raw;
 #pragma unroll
                                 for (int e = 0; e < EPO; ++e) v[e] = q3_to_f32(rr[e]);
                             } else {
 #pragma unroll
                                 for (int e = 0; e < EPO; ++e)
-                                    if (n + e < n_out) v[e] = q3_to_f32(Rb[(long long)m * p.ldr + n + e]);
+                                    if (n + e < n_out) v[e] = q3_to_f32(Rr[n + e]);
                             }
                         }
                         float* sp = slabA + row * SLD + ch * EPO;
@@ -491,17 +502,20 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
                 for (int id = lane; id < SROWS * cprw; id += 64) {
                     const int row = id / cprw, ch = id - row * cprw;
                     const int m = mrow0 + row, n = ncol0 + ch * EPO;
-                    if (m >= p.M || n >= n_out) continue;
-                    const long long yo = (long long)m * p.ldy + n;
+                    int bb, r;
+                    if (!locate(m, bb, r) || n >= n_out) continue;
+                    const long long yo = (long long)r * p.ldy + n;
+                    const bool blank = SEG && p.row_start && r < p.row_start[bb];   // rows before a stream's first sample
 #pragma unroll
                     for (int which = 0; which < 2; ++which) {
                         if (which == 1 && !Y2b) break;
                         const float* sp = (which ? slabB : slabA) + row * SLD + ch * EPO;
                         TO* dst = (which ? Y2b : Yb) + yo;
+                        if constexpr (SEG) dst += (long long)bb * (which ? p.y2_batch_stride : p.y_batch_stride);
                         float v[EPO];
 #pragma unroll
                         for (int e = 0; e < EPO; e += 4) {
-                            const float4 t4 = *(const float4*)(sp + e);
+                            const float4 t4 = blank ? make_float4(0.f, 0.f, 0.f, 0.f) : *(const float4*)(sp + e);
                             v[e] = t4.x; v[e + 1] = t4.y; v[e + 2] = t4.z; v[e + 3] = t4.w;
                         }
                         if (vec_ok) {
@@ -543,7 +557,10 @@ hipError_t launch_cfg(const ConvGemmArgs& a, hipStream_t s) {
     size_t lds = round_kb(region0) + 3 * round_kb((size_t)BN * BKB) + 1024;       // + a spare KiB for padding DMAs
     lds = std::max(lds, (size_t)NW * 2 * 16 * (32 * JG + 4) * sizeof(float));    // two wave-private 16-row epilogue slabs per wave
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = convgemm_kernel<TA, TO, WAVES_M, WAVES_N, WM, WN, BKB, FUSE2>;
+    const bool seg = a.seg_len > 0;
+    if (a.row_start && !seg) return hipErrorInvalidValue;
+    auto kern = seg ? convgemm_kernel<TA, TO, WAVES_M, WAVES_N, WM, WN, BKB, FUSE2, true>
+                    : convgemm_kernel<TA, TO, WAVES_M, WAVES_N, WM, WN, BKB, FUSE2, false>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -622,6 +639,8 @@ hipError_t q3_launch_convgemm(const ConvGemmArgs& a_in, int in_dtype, int out_dt
         return hipErrorInvalidValue;
     if (((uintptr_t)a.X | (uintptr_t)a.W | (uintptr_t)a.W2) & 15) return hipErrorInvalidValue;
     if (a.W2 && (a.N % epc_in)) return hipErrorInvalidValue;
+    if (a.seg_len > 0 && (a.B != 1 || a.seg_hist < 0 || a.seg_hist >= a.seg_len || a.M % a.seg_len)) return hipErrorInvalidValue;
+    if (!a.Y2) a.y2_batch_stride = 0;
     if (in_dtype == Q3_F32 && out_dtype == Q3_F32) return launch_typed<float, float, true>(a, s);
     if (in_dtype == Q3_BF16 && out_dtype == Q3_BF16) return launch_typed<bf16, bf16, true>(a, s);
     if (in_dtype == Q3_F32 && out_dtype == Q3_BF16) return launch_typed<float, bf16, false>(a, s);

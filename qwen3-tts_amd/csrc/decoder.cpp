@@ -250,6 +250,14 @@ struct GemmOpts {
     const Snake* post = nullptr;
     void* Y2 = nullptr;               // second output: Y gets the pre-`post` value, Y2 the post value
     const GemmW* second = nullptr;    // fused 1x1 second contraction (residual unit in one launch)
+    // Streaming layouts.  `segmented`: the B items' rows are stacked in one row space, each item = x_hist carried rows
+    // followed by its L_in new rows, and only new rows produce output.  Offsets / strides are in elements of the
+    // respective tensor; a stride of 0 means dense ([B][M][n_out]).
+    bool segmented = false;
+    int x_hist = 0;
+    int off_shift = 0;                // added to the layer's first tap offset
+    long long y_off = 0, y_bstride = 0, y2_off = 0, y2_bstride = 0, r_off = 0, r_bstride = 0;
+    const int* row_start = nullptr;   // [B]: output rows below it are stored as zeros
 };
 
 // X [B][L_in][K] contiguous -> Y [B][M][N_out] contiguous (N_out = N, or N/2 for SwiGLU); R like Y.
@@ -267,10 +275,21 @@ int gemm(q3c_ctx* c, const GemmW& g, const void* X, int B, int L_in, void* Y, in
     if (o.epi) { a.epi_a = o.epi->a; a.epi_invb = o.epi->invb; }
     a.scale = o.scale;
     if (o.post) { a.post_a = o.post->a; a.post_invb = o.post->invb; }
-    a.Y2 = o.Y2;
+    a.Y2 = o.Y2; a.y2_batch_stride = a.y_batch_stride;
     a.zeros = c->zero_page;
+    a.row_start = o.row_start;
     if (o.second) { a.W2 = o.second->w; a.bias2 = o.second->bias; }
-    if (g.taps == 1 && M == L_in) {      // no halo: batch items are just more rows
+    if (o.segmented) {
+        if (M != L_in) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "segmented contraction needs as many output as input rows");
+        const size_t eo = esize(out_dtype);
+        a.seg_len = o.x_hist + L_in; a.seg_hist = o.x_hist;
+        a.B = 1; a.M = B * a.seg_len; a.L_in = a.M; a.x_batch_stride = 0;
+        a.off0 = g.off0 + o.off_shift;
+        a.Y = (char*)Y + o.y_off * eo;
+        if (o.y_bstride) a.y_batch_stride = o.y_bstride;
+        if (o.Y2) { a.Y2 = (char*)o.Y2 + o.y2_off * eo; a.y2_batch_stride = o.y2_bstride ? o.y2_bstride : a.y2_batch_stride; }
+        if (o.R) { a.R = (const char*)o.R + o.r_off * eo; if (o.r_bstride) a.r_batch_stride = o.r_bstride; }
+    } else if (g.taps == 1 && M == L_in) {      // no halo: batch items are just more rows
         a.M = B * M; a.L_in = B * L_in; a.B = 1;
     }
     const char* pname = "";
@@ -278,14 +297,14 @@ int gemm(q3c_ctx* c, const GemmW& g, const void* X, int B, int L_in, void* Y, in
         pname = q3_convgemm_variant(a, g.in_dtype, out_dtype);
         if (c->profile_detail) {      // one entry per layer shape: interned so the pointer outlives this call
             char buf[64];
-            std::snprintf(buf, sizeof(buf), "%.24s M%dxN%dxK%dxT%d%s", pname + 9, a.B * a.M, a.N, a.K, a.taps, o.second ? "+1x1" : "");
+            std::snprintf(buf, sizeof(buf), "%.24s M%dxN%dxK%dxT%d%s", pname + 9, B * M, a.N, a.K, a.taps, o.second ? "+1x1" : "");
             pname = c->interned.insert(buf).first->c_str();
         }
     }
     // algorithmic bytes: input, weights, and each output / residual tensor once
     const double abytes = (double)B * L_in * g.K * esize(g.in_dtype) + (double)g.taps * g.N * g.K * esize(g.in_dtype) +
                           (double)B * M * n_out * esize(out_dtype) * (1 + (o.Y2 ? 1 : 0) + (o.R ? 1 : 0));
-    ProfScope ps(c, s, pname, 2.0 * a.B * a.M * (double)a.N * (a.K * a.taps + (o.second ? a.N : 0)), abytes);
+    ProfScope ps(c, s, pname, 2.0 * B * M * (double)a.N * (a.K * a.taps + (o.second ? a.N : 0)), abytes);
     hipError_t e = q3_launch_convgemm(a, g.in_dtype, out_dtype, s);
     if (e != hipSuccess) return fail(c, Q3C_ERR_HIP, std::string("convgemm launch: ") + hipGetErrorString(e));
     return 0;
@@ -381,6 +400,247 @@ int validate_config(q3c_ctx* c) {
     if (k.intermediate_size % 32) return fail(c, Q3C_ERR_UNSUPPORTED, "intermediate_size must be a multiple of 32");
     if (k.decoder_dim % (1 << k.num_upsample_rates)) return bad("decoder_dim not divisible by 2^blocks");
     if (k.sliding_window < 1 || k.sliding_window > 256) return fail(c, Q3C_ERR_UNSUPPORTED, "sliding_window must be in [1, 256]");
+    return 0;
+}
+
+
+// =========================================================================================================
+// Streaming decode.  Every layer of the decode is causal, so a stream can be advanced a few frames at a time and
+// produce exactly the samples of the un-chunked forward, provided each look-back (conv taps, the previous input row
+// of a transposed conv, the attention window) finds the rows of the previous pushes.  Those carried rows are the
+// per-slot state record; a push over S slots stacks [carried | new] rows of all S streams in one row space per
+// layer, so one launch per layer serves every stream whatever its position.
+//
+// A transposed conv with kernel 2r, stride r emits, for new input rows x[a..a+n), the r-row groups that need
+// (x[j-1], x[j]); the group of (nothing, x[0]) is what the reference trims on the left, so on a stream's first push
+// the leading rows of every later stage do not exist: they are stored as zeros (exactly the zero padding the causal
+// convs of the un-chunked forward see there) and the first `trim` samples of the first push are blank.
+// =========================================================================================================
+struct StreamPlan { size_t ws_bytes = 0; Q3CarryDesc* descs = nullptr; int ndesc = 0; };
+
+}  // namespace
+
+struct q3c_stream_pool {
+    q3c_ctx* c = nullptr;
+    int capacity = 0;
+    char* state = nullptr;
+    long long slot_stride = 0;
+    int* pos = nullptr;
+    std::map<std::pair<int, int>, StreamPlan> plans;
+    std::vector<void*> allocs;
+};
+
+namespace {
+
+struct SBuf { size_t off; int hist, rows, ch; size_t es; };   // per item: (hist + rows) rows of ch elements
+
+// The launch sequence of one push; with run == false it only lays out the workspace and lists the carried tensors.
+int stream_sequence(q3c_stream_pool* P, int S, int n, bool run, const StreamPlan* plan, const int* slots, const int64_t* codes,
+                    float* wav, char* ws, hipStream_t s, std::vector<Q3CarryDesc>* descs, size_t* ws_total, long long* state_total) {
+    q3c_ctx* c = P->c;
+    const q3c_config& k = c->cfg;
+    const int dt = c->dtype;
+    const size_t es = esize(dt);
+    size_t off = 0;
+    long long st_off = 0;
+    auto alloc = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
+    auto carried = [&](const SBuf& b, int col_off_elems, int cols) {
+        Q3CarryDesc d{};
+        d.work_off = (long long)b.off; d.work_bstride = (long long)(b.hist + b.rows) * b.ch * b.es;
+        d.state_off = st_off; d.work_ld = (int)(b.ch * b.es); d.col_off = (int)(col_off_elems * b.es); d.row_bytes = (int)(cols * b.es);
+        d.rows = b.hist; d.new_rows = b.rows;
+        if (descs) descs->push_back(d);
+        st_off += (long long)align_up((size_t)d.rows * d.row_bytes, 16);
+    };
+    auto tensor = [&](int hist, int rows, int ch, size_t e, int carry_col = 0, int carry_cols = -1) {
+        SBuf b{alloc((size_t)S * (hist + rows) * ch * e), hist, rows, ch, e};
+        if (hist) carried(b, carry_col, carry_cols < 0 ? ch : carry_cols);
+        return b;
+    };
+    auto ptr = [&](const SBuf& b) { return (void*)(ws + b.off); };
+    // output / residual placement of a tensor with carried rows, in elements
+    auto new_rows_off = [](const SBuf& b) { return (long long)b.hist * b.ch; };
+    auto item_stride = [](const SBuf& b) { return (long long)(b.hist + b.rows) * b.ch; };
+
+    const int nb = k.num_upsample_rates;
+    const size_t o_pos0 = alloc((size_t)S * 4);
+    const size_t o_rs = alloc((size_t)S * 4 * 2 * nb);
+    int* pos0 = (int*)(ws + o_pos0);
+    int* rs_all = (int*)(ws + o_rs);
+    Q3StageStarts st{};
+    st.count = 2 * nb;
+    {
+        int d_in = 0;
+        for (int i = 0; i < nb; ++i) { st.rows[2 * i] = d_in + 1; d_in = (d_in + 1) * k.upsample_rates[i]; st.rows[2 * i + 1] = d_in; }
+    }
+    if (run) {
+        LAUNCH(c, q3_launch_stream_prep(slots, S, P->capacity, P->pos, n, k.max_positions, pos0, rs_all, st, c->err_flag, s));
+        LAUNCH_B(c, s, "stream_carry", 2.0 * S * P->slot_stride,
+                 q3_launch_stream_carry(plan->descs, plan->ndesc, ws, P->state, P->slot_stride, slots, S, P->capacity, 0, s));
+    }
+
+    const int H = k.hidden_size, Lt = k.latent_dim;
+    const size_t fr = (size_t)S * n;
+    const size_t wmax = (size_t)std::max(Lt, H);
+    const size_t o_x = alloc(fr * wmax * es), o_nrm = alloc(fr * wmax * es);
+    void* bufA = ws + o_x; void* bufB = ws + o_nrm;
+
+    // ---- front end ----
+    if (k.frontend == Q3C_FRONTEND_MEAN_EMBEDDING) {
+        if (run) LAUNCH_B(c, s, "mean_embedding", fr * ((size_t)k.num_quantizers * (8 + H * 4) + H * es),
+                          q3_launch_mean_embedding((const long long*)codes, S, k.num_quantizers, n, k.codebook_size, H, c->emb_table, bufA,
+                                                   dt, c->err_flag, s));
+    } else {
+        const size_t o_sum = alloc(fr * c->G * k.codebook_dim * 4);
+        SBuf qb = tensor(k.pre_conv_kernel - 1, n, k.rvq_out_dim, es);
+        if (run) {
+            LAUNCH_B(c, s, "rvq_gather_sum", fr * ((size_t)k.num_quantizers * (8 + k.codebook_dim * 4) + (size_t)c->G * k.codebook_dim * 4),
+                     q3_launch_rvq_gather_sum((const long long*)codes, S, k.num_quantizers, n, k.codebook_size, k.codebook_dim,
+                                              c->tables_dev, c->group_start_dev, c->G, (float*)(ws + o_sum), c->err_flag, s));
+            GemmOpts g; g.segmented = true; g.y_off = new_rows_off(qb); g.y_bstride = item_stride(qb);
+            TRY(gemm(c, c->rvq_proj, ws + o_sum, S, n, ptr(qb), n, dt, g, s));
+            GemmOpts g2; g2.segmented = true; g2.x_hist = qb.hist;
+            TRY(gemm(c, c->pre_conv, ptr(qb), S, n, bufA, n, dt, g2, s));
+        }
+    }
+    // ---- transformer ----
+    void* x = bufA; void* nrm = bufB;
+    if (k.io_proj) { if (run) TRY(gemm(c, c->in_proj, bufA, S, n, bufB, n, dt, GemmOpts{}, s)); x = bufB; nrm = bufA; }
+    const int qd = k.num_attention_heads * k.head_dim, kvd = k.num_key_value_heads * k.head_dim;
+    const size_t o_att = alloc(fr * qd * es), o_mlp = alloc(fr * k.intermediate_size * es);
+    for (int l = 0; l < k.num_hidden_layers; ++l) {
+        const Layer& y = c->layers[l];
+        SBuf qkv = tensor(k.sliding_window - 1, n, qd + 2 * kvd, es, qd, 2 * kvd);     // only K and V rows are carried
+        if (!run) continue;
+        LAUNCH_B(c, s, "rmsnorm", 2 * fr * H * es, q3_launch_rmsnorm(x, y.ln1, nrm, (long long)fr, H, k.rms_norm_eps, dt, s));
+        GemmOpts gq; gq.segmented = true; gq.y_off = new_rows_off(qkv); gq.y_bstride = item_stride(qkv);
+        TRY(gemm(c, y.qkv, nrm, S, n, ptr(qkv), n, dt, gq, s));
+        LAUNCH_B(c, s, "swa_attention", fr * (size_t)(2 * qd + 2 * kvd) * es,
+                 q3_launch_swa_attention(ptr(qkv), ws + o_att, c->cos_t, c->sin_t, S, n, k.num_attention_heads, k.num_key_value_heads,
+                                         k.head_dim, k.sliding_window, dt, s, qkv.hist, pos0, k.max_positions));
+        GemmOpts o1; o1.scale = y.ls_attn; o1.R = x;
+        TRY(gemm(c, y.o, ws + o_att, S, n, x, n, dt, o1, s));
+        LAUNCH_B(c, s, "rmsnorm", 2 * fr * H * es, q3_launch_rmsnorm(x, y.ln2, nrm, (long long)fr, H, k.rms_norm_eps, dt, s));
+        GemmOpts o2; o2.act = Q3_ACT_SWIGLU;
+        TRY(gemm(c, y.gu, nrm, S, n, ws + o_mlp, n, dt, o2, s));
+        GemmOpts o3; o3.scale = y.ls_mlp; o3.R = x;
+        TRY(gemm(c, y.down, ws + o_mlp, S, n, x, n, dt, o3, s));
+    }
+    if (run) LAUNCH_B(c, s, "rmsnorm", 2 * fr * H * es, q3_launch_rmsnorm(x, c->final_norm, nrm, (long long)fr, H, k.rms_norm_eps, dt, s));
+    void* cur;
+    if (k.io_proj) { if (run) TRY(gemm(c, c->out_proj, nrm, S, n, x, n, dt, GemmOpts{}, s)); cur = x; }
+    else cur = nrm;
+
+    // ---- upsample stages ----
+    int L = n;
+    SBuf conv_in_x{};
+    const int nu = k.num_upsampling_ratios;
+    if (nu == 0) {
+        conv_in_x = tensor(6, L, Lt, es);
+        if (run) HIPCHK(c, hipMemcpy2DAsync((char*)ptr(conv_in_x) + new_rows_off(conv_in_x) * es, item_stride(conv_in_x) * es, cur,
+                                            (size_t)L * Lt * es, (size_t)L * Lt * es, S, hipMemcpyDeviceToDevice, s));
+    }
+    for (int i = 0; i < nu; ++i) {
+        const UpStage& u = c->ups[i];
+        const int Lf = L * u.f;
+        SBuf d_in = tensor(6, Lf, Lt, es);                       // the stage's transposed-conv output: depthwise conv looks back 6 rows
+        const size_t o_d = alloc((size_t)S * Lf * Lt * es), o_pw = alloc((size_t)S * Lf * 4 * Lt * es);
+        const bool last = i + 1 == nu;
+        size_t o_next = 0;
+        if (last) conv_in_x = tensor(6, Lf, Lt, es); else o_next = alloc((size_t)S * Lf * Lt * es);
+        if (run) {
+            GemmOpts g0; g0.segmented = true; g0.y_off = new_rows_off(d_in); g0.y_bstride = item_stride(d_in);
+            TRY(gemm(c, u.tconv, cur, S, L, ptr(d_in), L, dt, g0, s));
+            LAUNCH_B(c, s, "dwconv_ln", 2 * (size_t)S * Lf * Lt * es,
+                     q3_launch_dwconv_ln(ptr(d_in), u.dw_w, u.dw_b, u.ln_w, u.ln_b, ws + o_d, S, Lf, Lt, 7, k.convnext_eps, dt, s, d_in.hist));
+            GemmOpts g1; g1.act = Q3_ACT_GELU;
+            TRY(gemm(c, u.pw1, ws + o_d, S, Lf, ws + o_pw, Lf, dt, g1, s));
+            GemmOpts g2; g2.segmented = true; g2.scale = u.gamma;
+            g2.R = ptr(d_in); g2.r_off = new_rows_off(d_in); g2.r_bstride = item_stride(d_in);
+            if (last) { g2.y_off = new_rows_off(conv_in_x); g2.y_bstride = item_stride(conv_in_x); }
+            TRY(gemm(c, u.pw2, ws + o_pw, S, Lf, last ? ptr(conv_in_x) : (void*)(ws + o_next), Lf, dt, g2, s));
+        }
+        cur = ws + o_next;
+        L = Lf;
+    }
+
+    // ---- conv decoder ----
+    SBuf t_in = tensor(1, L, k.decoder_dim, es);                  // input of block 0's transposed conv (its SnakeBeta applied)
+    if (run) {
+        GemmOpts g; g.segmented = true; g.x_hist = conv_in_x.hist; g.post = &c->blocks[0].head;
+        g.y_off = new_rows_off(t_in); g.y_bstride = item_stride(t_in);
+        TRY(gemm(c, c->conv_in, ptr(conv_in_x), S, L, ptr(t_in), L, dt, g, s));
+    }
+    int ch = k.decoder_dim;
+    for (int i = 0; i < nb; ++i) {
+        const Block& b = c->blocks[i];
+        ch /= 2;
+        const int Lr = L * b.rate;
+        const int* rs_t = rs_all + (size_t)(2 * i) * S;
+        const int* rs_u = rs_all + (size_t)(2 * i + 1) * S;
+        const size_t o_raw = alloc((size_t)S * Lr * ch * es);
+        const bool fuse = c->fuse_units && q3_convgemm_fusable(ch, dt);
+        const size_t o_h = fuse ? 0 : alloc((size_t)S * Lr * ch * es);
+        void* raw = ws + o_raw;
+        SBuf u_in = tensor(6 * k.dilations[0], Lr, ch, es);
+        if (run) {
+            // [previous | new] input rows: group j of r output rows needs rows j-1 and j
+            GemmOpts g; g.segmented = true; g.x_hist = 1; g.off_shift = -1; g.post = &b.first_act_tiled; g.row_start = rs_t;
+            g.Y2 = ptr(u_in); g.y2_off = new_rows_off(u_in); g.y2_bstride = item_stride(u_in);
+            TRY(gemm(c, b.tconv, ptr(t_in), S, L, raw, L, dt, g, s));
+        }
+        L = Lr;
+        for (size_t j = 0; j < b.units.size(); ++j) {
+            const Unit& u = b.units[j];
+            const bool last = j + 1 == b.units.size();
+            const Snake* post = !last ? &b.units[j + 1].a1 : ((i + 1 < nb) ? &c->blocks[i + 1].head : &c->final_snake);
+            SBuf next = last ? tensor(i + 1 < nb ? 1 : 6, L, ch, es) : tensor(6 * k.dilations[j + 1], L, ch, es);
+            if (run) {
+                GemmOpts g; g.segmented = true; g.R = raw; g.post = post; g.row_start = rs_u;
+                void* Y;
+                if (last) { Y = ptr(next); g.y_off = new_rows_off(next); g.y_bstride = item_stride(next); }
+                else { Y = raw; g.Y2 = ptr(next); g.y2_off = new_rows_off(next); g.y2_bstride = item_stride(next); }
+                if (fuse) {
+                    g.x_hist = u_in.hist; g.act = Q3_ACT_SNAKE; g.epi = &u.a2; g.second = &u.c2;
+                    TRY(gemm(c, u.c1, ptr(u_in), S, L, Y, L, dt, g, s));
+                } else {
+                    GemmOpts g1; g1.segmented = true; g1.x_hist = u_in.hist; g1.act = Q3_ACT_SNAKE; g1.epi = &u.a2;
+                    TRY(gemm(c, u.c1, ptr(u_in), S, L, ws + o_h, L, dt, g1, s));
+                    TRY(gemm(c, u.c2, ws + o_h, S, L, Y, L, dt, g, s));
+                }
+            }
+            u_in = next;
+        }
+        t_in = u_in;
+    }
+    if (run) {   // final conv to one channel, clamp fused, fp32 samples out
+        GemmOpts g; g.segmented = true; g.x_hist = t_in.hist; g.act = Q3_ACT_CLAMP; g.row_start = rs_all + (size_t)(2 * nb - 1) * S;
+        TRY(gemm(c, c->conv_out, ptr(t_in), S, L, wav, L, Q3_F32, g, s));
+        LAUNCH_B(c, s, "stream_carry", 2.0 * S * P->slot_stride,
+                 q3_launch_stream_carry(plan->descs, plan->ndesc, ws, P->state, P->slot_stride, slots, S, P->capacity, 1, s));
+    }
+    if (ws_total) *ws_total = off;
+    if (state_total) *state_total = st_off;
+    return 0;
+}
+
+int stream_plan(q3c_stream_pool* P, int S, int n, const StreamPlan** out) {
+    q3c_ctx* c = P->c;
+    auto it = P->plans.find({S, n});
+    if (it == P->plans.end()) {
+        std::vector<Q3CarryDesc> descs;
+        StreamPlan pl;
+        long long st = 0;
+        TRY(stream_sequence(P, S, n, false, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &descs, &pl.ws_bytes, &st));
+        if (st > P->slot_stride) return fail(c, Q3C_ERR_STATE, "stream state record size changed");
+        void* p = nullptr;
+        HIPCHK(c, hipMalloc(&p, descs.size() * sizeof(Q3CarryDesc)));
+        P->allocs.push_back(p);
+        HIPCHK(c, hipMemcpy(p, descs.data(), descs.size() * sizeof(Q3CarryDesc), hipMemcpyHostToDevice));
+        pl.descs = (Q3CarryDesc*)p; pl.ndesc = (int)descs.size();
+        it = P->plans.emplace(std::make_pair(S, n), pl).first;
+    }
+    *out = &it->second;
     return 0;
 }
 
@@ -609,7 +869,9 @@ int q3c_check_errors(q3c_ctx* c, void* stream) {
     HIPCHK(c, hipStreamSynchronize((hipStream_t)stream));
     if (flag) {
         HIPCHK(c, hipMemsetAsync(c->err_flag, 0, sizeof(int), (hipStream_t)stream));
-        return fail(c, Q3C_ERR_CODES, "a code index was outside [0, codebook_size)");
+        if (flag & 1) return fail(c, Q3C_ERR_CODES, "a code index was outside [0, codebook_size)");
+        if (flag & 2) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "a stream slot id was outside the pool");
+        return fail(c, Q3C_ERR_INVALID_ARGUMENT, "a stream ran past max_positions frames");
     }
     return 0;
 }
@@ -787,6 +1049,76 @@ int q3c_profile_read(q3c_ctx* c, q3c_profile_entry* out, int32_t cap, int32_t* c
     for (auto& kv : agg) { if (n < cap) out[n++] = kv.second; }
     *count = n;
     return 0;
+}
+
+
+// ---- streaming ------------------------------------------------------------------------------------------------
+int q3c_stream_pool_create(q3c_ctx* c, int32_t capacity, q3c_stream_pool** out) {
+    if (!c || !out) return Q3C_ERR_INVALID_ARGUMENT;
+    if (!c->finalized) return fail(c, Q3C_ERR_STATE, "q3c_finalize has not run");
+    if (capacity < 1) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "stream pool capacity must be >= 1");
+    for (int i = 0; i < c->cfg.num_dilations; ++i)
+        if (c->cfg.dilations[i] < 1) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "dilations must be >= 1");
+    q3c_stream_pool* P = new q3c_stream_pool();
+    P->c = c; P->capacity = capacity;
+    long long st = 0;
+    int rc = stream_sequence(P, 1, 1, false, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &st);
+    if (rc) { delete P; return rc; }
+    P->slot_stride = (long long)align_up((size_t)st, 256);
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, (size_t)P->slot_stride * capacity);
+    if (e == hipSuccess) { P->allocs.push_back(p); P->state = (char*)p; e = hipMemset(p, 0, (size_t)P->slot_stride * capacity); }
+    if (e == hipSuccess) e = hipMalloc(&p, (size_t)capacity * 4);
+    if (e == hipSuccess) { P->allocs.push_back(p); P->pos = (int*)p; e = hipMemset(p, 0, (size_t)capacity * 4); }
+    if (e != hipSuccess) {
+        for (void* q : P->allocs) (void)hipFree(q);
+        delete P;
+        return fail(c, Q3C_ERR_HIP, std::string("stream pool allocation: ") + hipGetErrorString(e));
+    }
+    *out = P;
+    return 0;
+}
+
+void q3c_stream_pool_destroy(q3c_stream_pool* P) {
+    if (!P) return;
+    for (void* q : P->allocs) (void)hipFree(q);
+    delete P;
+}
+
+int q3c_stream_state_bytes(const q3c_stream_pool* P, size_t* per_slot) {
+    if (!P || !per_slot) return Q3C_ERR_INVALID_ARGUMENT;
+    *per_slot = (size_t)P->slot_stride;
+    return 0;
+}
+
+int q3c_stream_reset(q3c_stream_pool* P, const int32_t* slots, int32_t count, void* stream) {
+    if (!P) return Q3C_ERR_INVALID_ARGUMENT;
+    q3c_ctx* c = P->c;
+    if (!slots || count < 1) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "q3c_stream_reset: bad argument");
+    LAUNCH(c, q3_launch_stream_reset(slots, count, P->capacity, P->state, P->slot_stride, P->pos, c->err_flag, (hipStream_t)stream));
+    return 0;
+}
+
+int q3c_stream_workspace_bytes(q3c_stream_pool* P, int32_t S, int32_t n, size_t* bytes) {
+    if (!P || !bytes) return Q3C_ERR_INVALID_ARGUMENT;
+    if (S < 1 || n < 1) return fail(P->c, Q3C_ERR_INVALID_ARGUMENT, "streams and frames must be >= 1");
+    const StreamPlan* pl;
+    TRY(stream_plan(P, S, n, &pl));
+    *bytes = pl->ws_bytes;
+    return 0;
+}
+
+int q3c_stream_push(q3c_stream_pool* P, const int32_t* slots, int32_t S, const int64_t* codes, int32_t n, float* wav, void* ws,
+                    size_t ws_bytes, void* stream) {
+    if (!P) return Q3C_ERR_INVALID_ARGUMENT;
+    q3c_ctx* c = P->c;
+    if (!slots || !codes || !wav || !ws || S < 1 || n < 1) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "q3c_stream_push: bad argument");
+    if (S > P->capacity) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "more streams in one push than the pool holds");
+    if ((uintptr_t)ws & 255) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "workspace must be 256-byte aligned");
+    const StreamPlan* pl;
+    TRY(stream_plan(P, S, n, &pl));
+    if (ws_bytes < pl->ws_bytes) return fail(c, Q3C_ERR_WORKSPACE, "workspace too small: need " + std::to_string(pl->ws_bytes));
+    return stream_sequence(P, S, n, true, pl, slots, codes, wav, (char*)ws, (hipStream_t)stream, nullptr, nullptr, nullptr);
 }
 
 // ---- single operators ---------------------------------------------------------------------------------------

@@ -2,6 +2,7 @@
 // sliding-window attention with fused RoPE, the final 1-channel conv + clamp, and small utilities.
 // All tensors are channels-last [batch, time, channel].
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -92,11 +93,13 @@ template <typename T, int CPT>
 __global__ void __launch_bounds__(256) dwconv_ln_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, const float* __restrict__ lnw,
                                                         const float* __restrict__ lnb, T* __restrict__ y, int L, int C, int k,
-                                                        float eps) {
+                                                        float eps, int hist) {
     __shared__ float red[8];
     const long long row = blockIdx.x;            // b * L + t
     const int t = (int)(row % L);
     const int tid = threadIdx.x;
+    // x holds `hist` carried rows in front of each item's L rows (hist = 0: rows before the sequence are zero padding)
+    const T* xb = x + ((row / L) * (long long)(hist + L) + hist) * C;
     float v[CPT];
     float s = 0.f;
 #pragma unroll
@@ -107,7 +110,7 @@ __global__ void __launch_bounds__(256) dwconv_ln_kernel(const T* __restrict__ x,
             a = bias[c];
             for (int j = 0; j < k; ++j) {
                 int tt = t - (k - 1) + j;
-                if (tt >= 0) a += w[j * C + c] * q3_to_f32(x[(row - t + tt) * C + c]);
+                if (tt >= -hist) a += w[j * C + c] * q3_to_f32(xb[(long long)tt * C + c]);
             }
             s += a;
         }
@@ -146,14 +149,19 @@ constexpr int ATT_MAXC = 4;   // window <= 64 * ATT_MAXC
 template <typename T>
 __global__ void __launch_bounds__(256) swa_attention_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                             const float* __restrict__ cos_t, const float* __restrict__ sin_t,
-                                                            int Tn, int nh, int nkv, int d, int window, float scale) {
+                                                            int Tn, int nh, int nkv, int d, int window, float scale, int hist,
+                                                            const int* __restrict__ pos0, int max_pos) {
+    // Each item's qkv buffer holds `hist` carried rows then its new rows (Tn rows in all); only the new rows are
+    // queries.  Row r is frame pos0[b] - hist + r of its stream; rows of negative frame number do not exist yet.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_att[];
-    const int q0 = blockIdx.x * ATT_QT;
+    const int q0 = hist + blockIdx.x * ATT_QT;
     const int h = blockIdx.y, b = blockIdx.z;
+    const int shift = pos0 ? pos0[b] - hist : 0;
+    const int r_min = max(0, -shift);
     const int hk = h / (nh / nkv);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q_hi = min(q0 + ATT_QT, Tn) - 1;
-    const int k_lo = max(0, q0 - window + 1);
+    const int k_lo = max(r_min, q0 - window + 1);
     const int nk = q_hi - k_lo + 1;
     const int nkmax = ATT_QT + window - 1;
     const int ds = d + 1;                          // padded row stride: lane = key reads hit distinct banks
@@ -170,7 +178,8 @@ __global__ void __launch_bounds__(256) swa_attention_kernel(const T* __restrict_
         int pos = k_lo + r;
         const T* kr = base + (size_t)pos * rs + (nh + hk) * d;
         const T* vr = kr + nkv * d;
-        float c = cos_t[(size_t)pos * half + e], s = sin_t[(size_t)pos * half + e];
+        const int ap = min(pos + shift, max_pos - 1);
+        float c = cos_t[(size_t)ap * half + e], s = sin_t[(size_t)ap * half + e];
         float x1 = q3_to_f32(kr[e]), x2 = q3_to_f32(kr[e + half]);
         Ks[r * ds + e] = x1 * c - x2 * s;
         Ks[r * ds + e + half] = x2 * c + x1 * s;
@@ -182,7 +191,8 @@ __global__ void __launch_bounds__(256) swa_attention_kernel(const T* __restrict_
         int r = i / half, e = i - r * half;
         int pos = q0 + r;
         const T* qr = base + (size_t)pos * rs + h * d;
-        float c = cos_t[(size_t)pos * half + e], s = sin_t[(size_t)pos * half + e];
+        const int ap = min(pos + shift, max_pos - 1);
+        float c = cos_t[(size_t)ap * half + e], s = sin_t[(size_t)ap * half + e];
         float x1 = q3_to_f32(qr[e]), x2 = q3_to_f32(qr[e + half]);
         Qs[r * d + e] = x1 * c - x2 * s;
         Qs[r * d + e + half] = x2 * c + x1 * s;
@@ -192,7 +202,7 @@ __global__ void __launch_bounds__(256) swa_attention_kernel(const T* __restrict_
     const int nchunk = (window + 63) >> 6;
     for (int qi = wave; qi < nq; qi += 4) {
         const int i = q0 + qi;
-        const int jlo = max(0, i - window + 1);
+        const int jlo = max(r_min, i - window + 1);
         const float* qv = Qs + qi * d;
         float sc[ATT_MAXC];
         float mx = -INFINITY;
@@ -231,7 +241,7 @@ __global__ void __launch_bounds__(256) swa_attention_kernel(const T* __restrict_
             float a = 0.f;
             const float* vr = Vs + (size_t)(jlo - k_lo) * ds + e;
             for (int j = 0; j < cnt; ++j) a += Ps[j] * vr[(size_t)j * ds];
-            out[((size_t)b * Tn + i) * (nh * d) + h * d + e] = q3_from_f32<T>(a);
+            out[((size_t)b * (Tn - hist) + (i - hist)) * (nh * d) + h * d + e] = q3_from_f32<T>(a);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -299,6 +309,53 @@ __global__ void __launch_bounds__(256) snake_kernel(const T* __restrict__ x, T* 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Stream state.  A stream's carried context (the last rows of every tensor a causal kernel looks back into) lives
+// in one contiguous record per stream slot; a push copies the records of the participating slots into the front
+// rows of the work buffers, runs the layers over [carried | new] rows, and copies the last rows back.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) stream_carry_kernel(const Q3CarryDesc* __restrict__ descs, char* __restrict__ work,
+                                                           char* __restrict__ state, long long slot_stride,
+                                                           const int* __restrict__ slots, int capacity, int save) {
+    const Q3CarryDesc d = descs[blockIdx.x];
+    const int b = blockIdx.y;
+    const int slot = min(max(slots[b], 0), capacity - 1);
+    const int ppr = d.row_bytes >> 4;
+    char* w0 = work + d.work_off + (long long)b * d.work_bstride + d.col_off + (save ? (long long)d.new_rows * d.work_ld : 0);
+    char* s0 = state + (long long)slot * slot_stride + d.state_off;
+    for (int id = threadIdx.x; id < d.rows * ppr; id += 256) {
+        const int row = id / ppr, ch = id - row * ppr;
+        uint4* wp = (uint4*)(w0 + (long long)row * d.work_ld + ch * 16);
+        uint4* sp = (uint4*)(s0 + (long long)row * d.row_bytes + ch * 16);
+        if (save) *sp = *wp; else *wp = *sp;
+    }
+}
+
+// pos0[b] = frames the stream has consumed so far; row_start[st][b] = rows of stage st that precede the stream's
+// first sample (only on a stream's first push); then the slot's frame counter advances by n.
+__global__ void stream_prep_kernel(const int* __restrict__ slots, int S, int capacity, int* __restrict__ pos, int n, int max_pos,
+                                   int* __restrict__ pos0, int* __restrict__ row_start, Q3StageStarts st, int* err_flag) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= S) return;
+    int slot = slots[b];
+    if (slot < 0 || slot >= capacity) { atomicOr(err_flag, 2); slot = min(max(slot, 0), capacity - 1); }
+    int p = pos[slot];
+    if (p + n > max_pos) { atomicOr(err_flag, 4); p = max(0, max_pos - n); }
+    pos0[b] = p;
+    for (int i = 0; i < st.count; ++i) row_start[i * S + b] = p == 0 ? st.rows[i] : 0;
+    pos[slot] = p + n;
+}
+
+__global__ void __launch_bounds__(256) stream_reset_kernel(const int* __restrict__ slots, int capacity, char* __restrict__ state,
+                                                           long long slot_stride, int* __restrict__ pos, int* err_flag) {
+    int slot = slots[blockIdx.y];
+    if (slot < 0 || slot >= capacity) { if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(err_flag, 2); return; }
+    uint4* sp = (uint4*)(state + (long long)slot * slot_stride);
+    const long long n16 = slot_stride >> 4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) sp[i] = make_uint4(0, 0, 0, 0);
+    if (blockIdx.x == 0 && threadIdx.x == 0) pos[slot] = 0;
+}
+
 inline unsigned grid_for(long long n, int per_block) {
     long long g = (n + per_block - 1) / per_block;
     return (unsigned)g;
@@ -342,12 +399,13 @@ hipError_t q3_launch_rmsnorm(const void* x, const float* w, void* y, long long r
 }
 
 hipError_t q3_launch_dwconv_ln(const void* x, const float* w, const float* b, const float* lnw, const float* lnb, void* y, int B,
-                               int L, int C, int k, float eps, int dtype, hipStream_t s) {
+                               int L, int C, int k, float eps, int dtype, hipStream_t s, int hist) {
+    if (hist < 0) return hipErrorInvalidValue;
     long long rows = (long long)B * L;
     if (rows == 0) return hipSuccess;
     if (C > 256 * 8) return hipErrorInvalidValue;
     dim3 grid((unsigned)rows);
-#define Q3_DW(TT, CPT) hipLaunchKernelGGL((dwconv_ln_kernel<TT, CPT>), grid, dim3(256), 0, s, (const TT*)x, w, b, lnw, lnb, (TT*)y, L, C, k, eps)
+#define Q3_DW(TT, CPT) hipLaunchKernelGGL((dwconv_ln_kernel<TT, CPT>), grid, dim3(256), 0, s, (const TT*)x, w, b, lnw, lnb, (TT*)y, L, C, k, eps, hist)
     const int cpt = (C + 255) / 256;
     if (dtype == Q3_BF16) {
         if (cpt <= 1) Q3_DW(bf16, 1); else if (cpt <= 4) Q3_DW(bf16, 4); else Q3_DW(bf16, 8);
@@ -359,8 +417,9 @@ hipError_t q3_launch_dwconv_ln(const void* x, const float* w, const float* b, co
 }
 
 hipError_t q3_launch_swa_attention(const void* qkv, void* out, const float* cos_t, const float* sin_t, int B, int T, int nh,
-                                   int nkv, int d, int window, int dtype, hipStream_t s) {
+                                   int nkv, int d, int window, int dtype, hipStream_t s, int hist, const int* pos0, int max_pos) {
     if (B == 0 || T == 0) return hipSuccess;
+    if (hist < 0 || max_pos < 1) return hipErrorInvalidValue;
     if (window < 1 || window > 64 * ATT_MAXC || (d & 1) || d > 256) return hipErrorInvalidValue;
     const int nkmax = ATT_QT + window - 1;
     size_t lds = ((size_t)2 * nkmax * (d + 1) + (size_t)ATT_QT * d + 4 * 64 * ATT_MAXC) * sizeof(float);
@@ -371,11 +430,11 @@ hipError_t q3_launch_swa_attention(const void* qkv, void* out, const float* cos_
     if (dtype == Q3_BF16) {
         auto k = swa_attention_kernel<bf16>;
         if (lds > 48 * 1024 && (e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const bf16*)qkv, (bf16*)out, cos_t, sin_t, T, nh, nkv, d, window, scale);
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const bf16*)qkv, (bf16*)out, cos_t, sin_t, hist + T, nh, nkv, d, window, scale, hist, pos0, max_pos);
     } else {
         auto k = swa_attention_kernel<float>;
         if (lds > 48 * 1024 && (e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const float*)qkv, (float*)out, cos_t, sin_t, T, nh, nkv, d, window, scale);
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const float*)qkv, (float*)out, cos_t, sin_t, hist + T, nh, nkv, d, window, scale, hist, pos0, max_pos);
     }
     return hipGetLastError();
 }
@@ -422,5 +481,31 @@ hipError_t q3_launch_snake(const void* x, void* y, const float* a, const float* 
         hipLaunchKernelGGL(snake_kernel<bf16>, dim3(g), dim3(256), 0, s, (const bf16*)x, (bf16*)y, a, invb, n, C);
     else
         hipLaunchKernelGGL(snake_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)x, (float*)y, a, invb, n, C);
+    return hipGetLastError();
+}
+
+hipError_t q3_launch_stream_carry(const Q3CarryDesc* descs_dev, int ndesc, void* work, void* state, long long slot_stride,
+                                  const int* slots, int S, int capacity, int save, hipStream_t s) {
+    if (ndesc == 0 || S == 0) return hipSuccess;
+    if (slot_stride & 15) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(stream_carry_kernel, dim3(ndesc, S), dim3(256), 0, s, descs_dev, (char*)work, (char*)state, slot_stride, slots,
+                       capacity, save);
+    return hipGetLastError();
+}
+
+hipError_t q3_launch_stream_prep(const int* slots, int S, int capacity, int* pos, int n, int max_pos, int* pos0, int* row_start,
+                                 const Q3StageStarts& st, int* err_flag, hipStream_t s) {
+    if (S == 0) return hipSuccess;
+    hipLaunchKernelGGL(stream_prep_kernel, dim3((S + 63) / 64), dim3(64), 0, s, slots, S, capacity, pos, n, max_pos, pos0, row_start, st,
+                       err_flag);
+    return hipGetLastError();
+}
+
+hipError_t q3_launch_stream_reset(const int* slots, int count, int capacity, void* state, long long slot_stride, int* pos,
+                                  int* err_flag, hipStream_t s) {
+    if (count == 0) return hipSuccess;
+    if (slot_stride & 15) return hipErrorInvalidValue;
+    const unsigned gx = (unsigned)std::min<long long>(64, (slot_stride / 16 + 255) / 256 + 1);
+    hipLaunchKernelGGL(stream_reset_kernel, dim3(gx, count), dim3(256), 0, s, slots, capacity, (char*)state, slot_stride, pos, err_flag);
     return hipGetLastError();
 }

@@ -38,6 +38,7 @@ class Decoder:
         self.cfg = cfg
         self.device = torch.device(device)
         self.precision = precision
+        self.max_positions = int(max_positions)
         self.max_frames_per_launch = int(max_frames_per_launch)
         self._lib = _lib.load()
         self._ctx = C.c_void_p()
@@ -66,8 +67,16 @@ class Decoder:
 
     def close(self) -> None:
         if getattr(self, "_ctx", None):
+            for pool in list(getattr(self, "_pools", [])):
+                pool.close()
             self._lib.q3c_destroy(self._ctx)
             self._ctx = C.c_void_p()
+
+    def open_streams(self, capacity: int) -> "StreamPool":
+        """A pool of `capacity` stream slots whose causal state lives in this GPU's memory (see StreamPool)."""
+        pool = StreamPool(self, capacity)
+        self.__dict__.setdefault("_pools", []).append(pool)
+        return pool
 
     def __del__(self):
         try:
@@ -266,6 +275,126 @@ class Decoder:
         for stage in list(self._taps):
             self._lib.q3c_set_tap(self._ctx, stage, None, 0)
         self._taps.clear()
+
+
+class StreamPool:
+    """Incremental decode of many concurrent streams.
+
+    The reference has no incremental decode: it runs the whole utterance through the tokenizer's decode and sends one
+    SSE `audio` event (reference server.py:299-335), and the sibling's chunked_decode (:3686-3696) recomputes 25 frames
+    per chunk.  Here a stream is advanced a few frames per push and the concatenation of its pushes equals the
+    un-chunked forward of all its frames (:3672-3684): the rows every causal layer looks back into are carried in a
+    per-slot state record in device memory, and one push serves any set of slots, at any positions, in one launch
+    sequence.
+
+        pool = decoder.open_streams(256)
+        sid = pool.open()
+        wav = pool.push([sid, ...], codes[S, Q, n])      # list of 1-D float32 device tensors
+        pool.close_stream(sid)
+
+    A stream's first push returns n*1920 - 555 samples (the decode's fixed lookahead), later pushes n*1920.
+    """
+
+    def __init__(self, decoder: "Decoder", capacity: int):
+        self.dec = decoder
+        self.capacity = int(capacity)
+        self._lib = decoder._lib
+        self._pool = C.c_void_p()
+        self._ws: Optional[torch.Tensor] = None
+        self._free = list(range(self.capacity - 1, -1, -1))
+        self._frames: Dict[int, int] = {}            # open slot -> frames pushed so far
+        with torch.cuda.device(decoder.device):
+            decoder._check(self._lib.q3c_stream_pool_create(decoder._ctx, self.capacity, C.byref(self._pool)))
+
+    def close(self) -> None:
+        if getattr(self, "_pool", None):
+            self._lib.q3c_stream_pool_destroy(self._pool)
+            self._pool = C.c_void_p()
+            if self in getattr(self.dec, "_pools", []):
+                self.dec._pools.remove(self)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def state_bytes_per_stream(self) -> int:
+        n = C.c_size_t()
+        self.dec._check(self._lib.q3c_stream_state_bytes(self._pool, C.byref(n)))
+        return int(n.value)
+
+    def open(self) -> int:
+        """Claims a slot and zeroes its state; returns the stream id."""
+        return self.open_many(1)[0]
+
+    def open_many(self, count: int) -> List[int]:
+        if count > len(self._free):
+            raise RuntimeError(f"stream pool is full ({self.capacity} slots)")
+        ids = [self._free.pop() for _ in range(count)]
+        dev = torch.tensor(ids, dtype=torch.int32, device=self.dec.device)
+        with torch.cuda.device(self.dec.device):
+            self.dec._check(self._lib.q3c_stream_reset(self._pool, C.c_void_p(dev.data_ptr()), count, self.dec._stream()))
+        for i in ids:
+            self._frames[i] = 0
+        return ids
+
+    def close_stream(self, sid: int) -> None:
+        if sid not in self._frames:
+            raise KeyError(f"stream {sid} is not open")
+        del self._frames[sid]
+        self._free.append(sid)
+
+    def frames_pushed(self, sid: int) -> int:
+        return self._frames[sid]
+
+    def push_raw(self, ids_dev: torch.Tensor, codes: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The launch sequence alone: ids_dev int32 [S] and codes int64 [S, Q, n] on the device -> [S, n*1920] float32
+        (a stream's first push starts with 555 blank samples).  No host bookkeeping and no synchronisation."""
+        dec = self.dec
+        S, Q, n = codes.shape
+        up = dec.cfg.total_upsample
+        if out is None:
+            out = torch.empty((S, n * up), dtype=torch.float32, device=dec.device)
+        with torch.cuda.device(dec.device):
+            need = C.c_size_t()
+            dec._check(self._lib.q3c_stream_workspace_bytes(self._pool, S, n, C.byref(need)))
+            if self._ws is None or self._ws.numel() < need.value + 256:
+                self._ws = None
+                self._ws = torch.empty(need.value + 256, dtype=torch.uint8, device=dec.device)
+            base = (self._ws.data_ptr() + 255) // 256 * 256
+            dec._check(self._lib.q3c_stream_push(self._pool, C.c_void_p(ids_dev.data_ptr()), S, C.c_void_p(codes.data_ptr()), n,
+                                                 C.c_void_p(out.data_ptr()), C.c_void_p(base),
+                                                 self._ws.numel() - (base - self._ws.data_ptr()), dec._stream()))
+        return out
+
+    def push(self, ids: Sequence[int], codes: torch.Tensor, check: bool = False) -> List[torch.Tensor]:
+        """Advance the streams `ids` (distinct, open) by n frames each: codes [S, Q, n].  Returns one 1-D float32
+        device tensor per stream with that stream's new samples."""
+        dec = self.dec
+        ids = [int(i) for i in ids]
+        codes = dec._codes_tensor(codes)
+        S, _, n = codes.shape
+        if S != len(ids) or n < 1:
+            raise ValueError(f"{len(ids)} stream ids for codes of shape {tuple(codes.shape)}")
+        if len(set(ids)) != S:
+            raise ValueError("stream ids in one push must be distinct")
+        for i in ids:
+            if i not in self._frames:
+                raise KeyError(f"stream {i} is not open")
+            if self._frames[i] + n > dec.max_positions:
+                raise ValueError(f"stream {i} would exceed max_positions = {dec.max_positions} frames")
+        ids_dev = torch.tensor(ids, dtype=torch.int32, device=dec.device)
+        wav = self.push_raw(ids_dev, codes)
+        if check:
+            with torch.cuda.device(dec.device):
+                dec._check(self._lib.q3c_check_errors(dec._ctx, dec._stream()))
+        out = []
+        for b, i in enumerate(ids):
+            out.append(wav[b, dec.cfg.trim:] if self._frames[i] == 0 else wav[b])
+            self._frames[i] += n
+        return out
 
 
 # ---- operator-level entry points (device fp32 tensors, channels-last) ------------------------------------

@@ -7,15 +7,20 @@ from qwen3_tts_amd import _lib
 import decoder_oracle as oracle
 
 
+def _host(x):
+    if isinstance(x, torch.Tensor):
+        x = x.detach().cpu()
+    return np.asarray(x, dtype=np.float64)
+
+
 def snr_db(ref, got):
-    ref = np.asarray(ref, dtype=np.float64)
-    got = np.asarray(got, dtype=np.float64)
+    ref, got = _host(ref), _host(got)
     noise = ((ref - got) ** 2).sum()
     return float("inf") if noise == 0 else 10.0 * np.log10((ref ** 2).sum() / noise)
 
 
 def max_abs(ref, got):
-    return float(np.abs(np.asarray(ref, dtype=np.float64) - np.asarray(got, dtype=np.float64)).max())
+    return float(np.abs(_host(ref) - _host(got)).max())
 
 
 def stage_report(dec, cfg, w, codes):

@@ -1,0 +1,147 @@
+"""Streaming decode on the GPU: the concatenated pushes of a stream must equal the un-chunked forward of all its frames
+(sibling Code2Wav.forward, modeling_qwen3_omni_moe.py:3672-3684), whatever the push sizes and whichever other streams
+share the launches.  fp32 bar: max-abs <= 1e-3 and SNR >= 60 dB against the CPU oracle (the same bar as the bulk path);
+against the library's own un-chunked forward the two differ only by which rows share a tile, so the bound there is 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+import qwen3_tts_amd as q3
+from qwen3_tts_amd import _lib
+from qwen3_tts_amd.decoder import Decoder
+
+from gpu_util import max_abs, oracle, snr_db
+
+pytestmark = pytest.mark.gpu
+
+
+def _decoder(cfg, precision="f32", seed=0, **kw):
+    w = q3.synthetic_weights(cfg, seed=seed)
+    return Decoder(cfg, w, device="cuda:0", precision=precision, **kw), w
+
+
+def _stream_all(pool, sid, codes, sizes):
+    """Push codes [Q, T] of one stream in pieces of the given sizes (cycled); returns the concatenated samples."""
+    out, t, i = [], 0, 0
+    T = codes.shape[-1]
+    while t < T:
+        n = min(sizes[i % len(sizes)], T - t)
+        out.append(pool.push([sid], codes[None, :, t:t + n])[0])
+        t += n
+        i += 1
+    return torch.cat(out)
+
+
+@pytest.mark.parametrize("frontend", ["split_rvq", "mean_embedding"])
+def test_single_stream_equals_unchunked_forward(frontend):
+    cfg = q3.tiny_config(frontend)
+    dec, w = _decoder(cfg)
+    T = 90
+    codes = q3.random_codes(cfg, 1, T, seed=5)
+    ref = dec.forward(codes)[0, 0]
+    want = oracle.forward(cfg, w, codes)[0, 0]
+    pool = dec.open_streams(4)
+    for sizes in ([1], [3, 1, 7, 2], [40, 50]):
+        sid = pool.open()
+        got = _stream_all(pool, sid, codes[0].cuda(), sizes)
+        pool.close_stream(sid)
+        assert got.shape == ref.shape == (cfg.output_length(T),)
+        assert max_abs(got, ref) <= 1e-5, (sizes, max_abs(got, ref))
+        assert max_abs(got.cpu(), want) <= 1e-3 and snr_db(want, got.cpu()) >= 60.0
+
+
+def test_six_hundred_frames_one_frame_at_a_time():
+    """Longer than the attention window, the chunk size of chunked_decode and several tiles of every layer."""
+    cfg = q3.tiny_config("split_rvq")
+    dec, w = _decoder(cfg)
+    T = 600
+    codes = q3.random_codes(cfg, 1, T, seed=2)
+    ref = dec.forward(codes)[0, 0]
+    pool = dec.open_streams(1)
+    sid = pool.open()
+    got = _stream_all(pool, sid, codes[0].cuda(), [1])
+    assert got.shape == ref.shape
+    assert max_abs(got, ref) <= 1e-5
+    want = oracle.forward(cfg, w, codes)[0, 0]
+    assert max_abs(got.cpu(), want) <= 1e-3 and snr_db(want, got.cpu()) >= 60.0
+
+
+def test_staggered_streams_share_launches():
+    """Streams at different positions, joining and leaving, in changing order, with slot reuse."""
+    cfg = q3.tiny_config("split_rvq")
+    dec, _ = _decoder(cfg)
+    rng = np.random.default_rng(0)
+    T = {0: 30, 1: 47, 2: 12, 3: 25}
+    codes = {k: q3.random_codes(cfg, 1, t, seed=10 + k)[0].cuda() for k, t in T.items()}
+    refs = {k: dec.forward(codes[k][None])[0, 0] for k in T}
+    pool = dec.open_streams(3)
+    sid, done, outs = {}, {k: 0 for k in T}, {k: [] for k in T}
+    waiting = [0, 1, 2, 3]
+    step = 0
+    while any(done[k] < T[k] for k in T):
+        while waiting and len(sid) < 3 and (step % 2 == 0 or not sid):      # stagger the openings
+            k = waiting.pop(0)
+            sid[k] = pool.open()
+        live = [k for k in sid if done[k] < T[k]]
+        n = int(rng.integers(1, 5))
+        group = [k for k in live if T[k] - done[k] >= n]
+        if not group:
+            n, group = 1, live
+        rng.shuffle(group)
+        batch = torch.stack([codes[k][:, done[k]:done[k] + n] for k in group])
+        for k, piece in zip(group, pool.push([sid[k] for k in group], batch, check=True)):
+            outs[k].append(piece)
+            done[k] += n
+        for k in list(sid):
+            if done[k] >= T[k]:
+                pool.close_stream(sid.pop(k))
+        step += 1
+    for k in T:
+        got = torch.cat(outs[k])
+        assert got.shape == refs[k].shape
+        assert max_abs(got, refs[k]) <= 1e-5, (k, max_abs(got, refs[k]))
+
+
+def test_streaming_wide_channels_bf16_matches_bulk_bf16():
+    """bf16 contexts round at the same places in both paths; the fused residual-unit kernels and the 8-wave tiles run."""
+    cfg = q3.tiny_config("split_rvq", decoder_dim=1536, latent_dim=256, hidden_size=256, intermediate_size=512)
+    dec, _ = _decoder(cfg, precision="bf16")
+    S, T = 3, 7
+    codes = q3.random_codes(cfg, S, T, seed=3).cuda()
+    ref = dec.forward(codes)[:, 0]
+    pool = dec.open_streams(S)
+    ids = pool.open_many(S)
+    parts = [pool.push(ids, codes[:, :, a:b]) for a, b in ((0, 2), (2, 3), (3, 7))]
+    for s in range(S):
+        got = torch.cat([p[s] for p in parts])
+        assert got.shape == ref[s].shape
+        err = max_abs(got, ref[s])
+        assert err <= 2e-2 and snr_db(ref[s], got) >= 40.0, (s, err, snr_db(ref[s], got))
+
+
+def test_stream_errors():
+    cfg = q3.tiny_config("split_rvq")
+    dec, _ = _decoder(cfg, max_positions=16)
+    pool = dec.open_streams(2)
+    a = pool.open()
+    b = pool.open()
+    with pytest.raises(RuntimeError):
+        pool.open()
+    with pytest.raises(ValueError):
+        pool.push([a, a], q3.random_codes(cfg, 2, 1, seed=0))
+    with pytest.raises(ValueError):
+        pool.push([a], q3.random_codes(cfg, 1, 17, seed=0))           # beyond max_positions
+    with pytest.raises(ValueError):
+        pool.push([a], torch.zeros((1, cfg.num_quantizers + 1, 2), dtype=torch.int64))
+    bad = q3.random_codes(cfg, 1, 2, seed=0)
+    bad[0, 1, 1] = cfg.codebook_size
+    with pytest.raises(IndexError):
+        pool.push([b], bad, check=True)
+    pool.close_stream(a)
+    with pytest.raises(KeyError):
+        pool.push([a], q3.random_codes(cfg, 1, 1, seed=0))
+    # a slot id outside the pool is caught on the device
+    ids = torch.tensor([7], dtype=torch.int32, device="cuda:0")
+    pool.push_raw(ids, q3.random_codes(cfg, 1, 1, seed=0).cuda())
+    with pytest.raises(_lib.Q3cError):
+        dec._check(dec._lib.q3c_check_errors(dec._ctx, dec._stream()))
