@@ -1,0 +1,160 @@
+"""Install the MI355X decode into a loaded Qwen3-TTS model.
+
+The reference never calls the speech tokenizer itself: it calls `Qwen3TTSModel.generate_voice_clone` /
+`generate_custom_voice` (reference server.py:245-251, models.py:86-101), which run the talker LM and then hand the
+generated codes to the tokenizer's `decode`.  Replacing that one bound method is therefore the whole integration:
+
+    model = Qwen3TTSModel.from_pretrained(path, device_map=..., dtype=...)     # reference models.py:43-48
+    install_decoder(model)                                                     # <- the one added line
+    wavs, sr = model.generate_voice_clone(...)                                 # unchanged
+
+The `qwen-tts` package is not available where this was written, so nothing here relies on its attribute names: the
+tokenizer object is found by shape (it owns a callable `decode` and a `decoder` sub-module whose state dict holds the
+decoder's tensors), the architecture is read from that sub-module's config and cross-checked against tensor shapes,
+and anything that does not line up raises instead of being guessed.
+"""
+from __future__ import annotations
+
+from typing import Any, Callable, Dict, Iterable, Optional, Tuple
+
+import torch
+
+from .config import DecoderConfig, FRONTEND_MEAN_EMBEDDING, FRONTEND_SPLIT_RVQ
+from .weights import param_specs
+
+_ANCHOR = "decoder.0.conv.weight"            # first conv of the conv decoder: present for every front end
+
+
+def _children(obj: Any) -> Iterable[Tuple[str, Any]]:
+    if isinstance(obj, torch.nn.Module):
+        yield from obj.named_children()
+    d = getattr(obj, "__dict__", None)
+    if isinstance(d, dict):
+        for k, v in d.items():
+            if k.startswith("__") or isinstance(v, (str, bytes, int, float, bool, torch.Tensor, type(None))):
+                continue
+            yield k, v
+
+
+def find_speech_tokenizer(model: Any, max_depth: int = 4) -> Tuple[Any, Any]:
+    """-> (tokenizer object, its decoder module).  Breadth-first over attributes; the tokenizer is the first object
+    with a callable `decode` and a `decoder` attribute whose state dict contains the conv decoder's first weight."""
+    seen, frontier = set(), [(model, 0)]
+    while frontier:
+        obj, depth = frontier.pop(0)
+        if id(obj) in seen:
+            continue
+        seen.add(id(obj))
+        dec = getattr(obj, "decoder", None)
+        if callable(getattr(obj, "decode", None)) and dec is not None and callable(getattr(dec, "state_dict", None)):
+            keys = dec.state_dict().keys()
+            if any(k == _ANCHOR or k.endswith("." + _ANCHOR) for k in keys):
+                return obj, dec
+        if depth < max_depth:
+            for _name, child in _children(obj):
+                if not isinstance(child, (list, tuple, dict, set)):
+                    frontier.append((child, depth + 1))
+    raise LookupError("no speech tokenizer found: expected an object with a `decode` method and a `decoder` module whose "
+                      f"state dict has '{_ANCHOR}'")
+
+
+def decoder_weights(decoder_module: Any) -> Dict[str, torch.Tensor]:
+    """The decoder's tensors under the names this package uses (the sibling Code2Wav's state-dict keys), with any
+    common prefix of the module's own keys removed."""
+    sd = dict(decoder_module.state_dict())
+    prefix = None
+    for k in sd:
+        if k == _ANCHOR or k.endswith("." + _ANCHOR):
+            prefix = k[: len(k) - len(_ANCHOR)]
+            break
+    if prefix is None:
+        raise KeyError(f"state dict has no '{_ANCHOR}'")
+    return {k[len(prefix):]: v.detach() for k, v in sd.items() if k.startswith(prefix)}
+
+
+def _get(cfg_obj: Any, name: str, default: Any = None) -> Any:
+    if isinstance(cfg_obj, dict):
+        return cfg_obj.get(name, default)
+    return getattr(cfg_obj, name, default)
+
+
+def config_from_weights(cfg_obj: Any, w: Dict[str, torch.Tensor]) -> DecoderConfig:
+    """Architecture from the module's config object (or dict), with every size that a tensor shape determines taken
+    from the shape; a disagreement between the two is an error."""
+    base = DecoderConfig()
+    fields: Dict[str, Any] = {}
+    for f in base.to_dict():
+        v = _get(cfg_obj, f)
+        if v is not None:
+            fields[f] = tuple(v) if isinstance(v, (list, tuple)) else v
+
+    def agree(name: str, value: Any) -> None:
+        if name in fields and fields[name] != value:
+            raise ValueError(f"decoder config says {name} = {fields[name]!r} but the weights imply {value!r}")
+        fields[name] = value
+
+    if "code_embedding.weight" in w:
+        agree("frontend", FRONTEND_MEAN_EMBEDDING)
+        agree("hidden_size", int(w["code_embedding.weight"].shape[1]))
+    elif "quantizer.semantic.layers.0.embed_sum" in w:
+        agree("frontend", FRONTEND_SPLIT_RVQ)
+        n_sem = sum(1 for k in w if k.startswith("quantizer.semantic.layers.") and k.endswith(".embed_sum"))
+        n_ac = sum(1 for k in w if k.startswith("quantizer.acoustic.layers.") and k.endswith(".embed_sum"))
+        bins, dim = w["quantizer.semantic.layers.0.embed_sum"].shape
+        agree("num_semantic_quantizers", n_sem)
+        agree("num_quantizers", n_sem + n_ac)
+        agree("codebook_size", int(bins))
+        agree("codebook_dim", int(dim))
+        agree("rvq_out_dim", int(w["quantizer.semantic.output_proj.weight"].shape[0]))
+        lt, _cin, k = w["pre_conv.conv.weight"].shape
+        agree("latent_dim", int(lt))
+        agree("pre_conv_kernel", int(k))
+    else:
+        raise KeyError("state dict has neither 'code_embedding.weight' nor 'quantizer.semantic.layers.0.embed_sum'")
+    agree("io_proj", "pre_transformer.input_proj.weight" in w)
+    n_layers = 0
+    while f"pre_transformer.layers.{n_layers}.input_layernorm.weight" in w:
+        n_layers += 1
+    agree("num_hidden_layers", n_layers)
+    if n_layers:
+        agree("hidden_size", int(w["pre_transformer.layers.0.input_layernorm.weight"].shape[0]))
+        agree("intermediate_size", int(w["pre_transformer.layers.0.mlp.gate_proj.weight"].shape[0]))
+    dd, lt, _k = w[_ANCHOR].shape
+    agree("decoder_dim", int(dd))
+    agree("latent_dim", int(lt))
+    cfg = DecoderConfig.from_dict(fields)
+    missing = [n for n, shape, _kind, _fan in param_specs(cfg) if n not in w or tuple(w[n].shape) != tuple(shape)]
+    if missing:
+        raise ValueError(f"{len(missing)} decoder tensors are missing or mis-shaped for the derived config, first: {missing[:4]}")
+    return cfg
+
+
+def install_decoder(model: Any, precision: str = "bf16", device: Optional[Any] = None,
+                    decoder_factory: Optional[Callable[..., Any]] = None, **decoder_kwargs: Any) -> Any:
+    """Find the model's speech tokenizer, build a `Decoder` from its weights on `device` (default: where those weights
+    live) and replace the tokenizer's `decode` with it.  The previous bound method stays reachable as
+    `tokenizer.reference_decode`.  Returns the new decoder."""
+    tok, dec_mod = find_speech_tokenizer(model)
+    w = decoder_weights(dec_mod)
+    cfg = config_from_weights(getattr(dec_mod, "config", None) or getattr(tok, "decoder_config", None) or {}, w)
+    if device is None:
+        device = next(iter(w.values())).device
+        if torch.device(device).type != "cuda":
+            raise RuntimeError("the model's decoder weights are not on a GPU; pass device='cuda:N' (there is no CPU fallback)")
+    if decoder_factory is None:
+        from .decoder import Decoder as decoder_factory          # noqa: N813  (needs the built library)
+    names = {n for n, *_ in param_specs(cfg)}
+    new = decoder_factory(cfg, {k: v for k, v in w.items() if k in names}, device=device, precision=precision, **decoder_kwargs)
+    if not hasattr(tok, "reference_decode"):
+        tok.reference_decode = tok.decode
+    tok.decode = new.decode
+    tok.q3c_decoder = new
+    return new
+
+
+def uninstall_decoder(model: Any) -> None:
+    tok, _ = find_speech_tokenizer(model)
+    if hasattr(tok, "reference_decode"):
+        tok.decode = tok.reference_decode
+        del tok.reference_decode
+        tok.q3c_decoder = None

@@ -225,3 +225,22 @@ def test_errors():
         _decoder(cfg, bad, "f32")
     with pytest.raises(IndexError):
         dec.decode(torch.full((4, cfg.num_quantizers), cfg.codebook_size, dtype=torch.int64))
+
+
+def test_torch_custom_ops_run_the_library():
+    """torch.ops.q3tts.* are the same entry points behind the dispatcher."""
+    from qwen3_tts_amd import torch_ops
+    cfg = q3.tiny_config("split_rvq")
+    w = q3.synthetic_weights(cfg, seed=0)
+    dec = Decoder(cfg, w, device="cuda:0", precision="f32")
+    h = torch_ops.register_decoder(dec)
+    codes = q3.random_codes(cfg, 2, 12, seed=9).cuda()
+    assert torch.equal(torch.ops.q3tts.decode_forward(codes, h), dec.forward(codes))
+    assert torch.equal(torch.ops.q3tts.rvq_dequant(codes, h), dec.rvq_dequant(codes))
+    assert torch.equal(torch.ops.q3tts.chunked_decode(codes, h, 8, 2), dec.chunked_decode(codes, 8, 2))
+    x = torch.randn(2, 40, 16, device="cuda")
+    wt = torch.randn(24, 16, 7)
+    want = oracle.causal_conv1d(x.cpu().transpose(1, 2), wt, None, 3).transpose(1, 2)
+    got = torch.ops.q3tts.causal_conv1d(x, wt, None, 3, "f32")
+    assert max_abs(want, got) <= 2e-5 * max(1.0, float(want.abs().max()))
+    torch_ops.unregister_decoder(h)

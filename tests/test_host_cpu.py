@@ -156,3 +156,105 @@ def test_sharded_decode_two_ranks_gloo():
         outs = [p.communicate(timeout=240)[0] for p in procs]
         for r, (p, o) in enumerate(zip(procs, outs)):
             assert p.returncode == 0, f"rank {r} failed:\n{o[-3000:]}"
+
+
+# ---- install hook (stub model: the real package is not installed here) ------------------------------------------
+class _StubDecoderModule:
+    def __init__(self, cfg, weights, prefix=""):
+        import types
+        self.config = types.SimpleNamespace(**{k: v for k, v in cfg.to_dict().items()
+                                               if k not in (("frontend", "io_proj", "codebook_dim", "rvq_out_dim")
+                                                            if cfg.frontend == "split_rvq" else ("frontend", "io_proj"))})
+        self._sd = {prefix + k: v for k, v in weights.items()}
+
+    def state_dict(self):
+        return self._sd
+
+
+class _StubTokenizer:
+    def __init__(self, decoder):
+        self.decoder = decoder
+
+    def decode(self, encoded):
+        return "reference", 24000
+
+
+class _StubInner(torch.nn.Module):
+    def __init__(self, tok):
+        super().__init__()
+        self.talker = torch.nn.Linear(2, 2)
+        self.speech_tokenizer = tok
+
+
+class _StubTTS:
+    def __init__(self, tok):
+        self.model = _StubInner(tok)
+        self.name = "stub"
+
+
+class _FakeDecoder:
+    def __init__(self, cfg, weights, device, precision, **kw):
+        self.cfg, self.weights, self.device, self.precision, self.kw = cfg, weights, device, precision, kw
+
+    def decode(self, encoded):
+        return "mi355x", self.cfg.sample_rate
+
+
+@pytest.mark.parametrize("frontend,prefix", [("split_rvq", ""), ("mean_embedding", "model.code2wav.")])
+def test_install_hook_finds_tokenizer_and_derives_config(frontend, prefix):
+    from qwen3_tts_amd import install
+    cfg = q3.tiny_config(frontend)
+    w = q3.synthetic_weights(cfg, seed=0)
+    extra = dict(w)
+    extra["unrelated.buffer"] = torch.zeros(3)
+    tok = _StubTokenizer(_StubDecoderModule(cfg, extra, prefix))
+    model = _StubTTS(tok)
+    new = install.install_decoder(model, precision="f32", device="cuda:0", decoder_factory=_FakeDecoder, max_positions=99)
+    assert new.cfg == cfg and new.precision == "f32" and new.kw == {"max_positions": 99}
+    assert set(new.weights) == set(w) and all(torch.equal(new.weights[k], w[k]) for k in w)
+    assert model.model.speech_tokenizer.decode([0]) == ("mi355x", 24000)
+    assert model.model.speech_tokenizer.reference_decode([0]) == ("reference", 24000)
+    install.uninstall_decoder(model)
+    assert model.model.speech_tokenizer.decode([0]) == ("reference", 24000)
+
+
+def test_install_hook_refuses_mismatches():
+    from qwen3_tts_amd import install
+    cfg = q3.tiny_config("split_rvq")
+    w = q3.synthetic_weights(cfg, seed=0)
+    with pytest.raises(LookupError):
+        install.find_speech_tokenizer(_StubTTS(object()))
+    bad = dict(w)
+    bad["decoder.1.block.2.conv1.conv.weight"] = torch.zeros(3, 3, 7)
+    with pytest.raises(ValueError, match="missing or mis-shaped"):
+        install.install_decoder(_StubTTS(_StubTokenizer(_StubDecoderModule(cfg, bad))), device="cuda:0", decoder_factory=_FakeDecoder)
+    mod = _StubDecoderModule(cfg, w)
+    mod.config.decoder_dim = cfg.decoder_dim * 2
+    with pytest.raises(ValueError, match="decoder_dim"):
+        install.install_decoder(_StubTTS(_StubTokenizer(mod)), device="cuda:0", decoder_factory=_FakeDecoder)
+    cpu_model = _StubTTS(_StubTokenizer(_StubDecoderModule(cfg, w)))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        install.install_decoder(cpu_model, decoder_factory=_FakeDecoder)
+
+
+# ---- torch custom ops: registration and shape functions (no GPU: the kernels themselves are CUDA-only) -------------
+def test_torch_ops_are_registered_with_shape_functions():
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from qwen3_tts_amd import torch_ops
+    import types
+    cfg = q3.tiny_config("split_rvq")
+    h = torch_ops.register_decoder(types.SimpleNamespace(cfg=cfg))
+    for name in ("decode_forward", "chunked_decode", "rvq_dequant", "causal_conv1d", "causal_trans_conv1d", "snake_beta"):
+        assert hasattr(torch.ops.q3tts, name)
+    with FakeTensorMode():
+        codes = torch.zeros((2, cfg.num_quantizers, 310), dtype=torch.int64)
+        assert torch.ops.q3tts.decode_forward(codes, h).shape == (2, 1, cfg.output_length(310))
+        assert torch.ops.q3tts.chunked_decode(codes, h, 300, 25).shape == (2, 1, cfg.chunked_output_length(310))
+        assert torch.ops.q3tts.rvq_dequant(codes, h).shape == (2, 310, 2, cfg.codebook_dim)
+        x = torch.zeros((2, 50, 16))
+        assert torch.ops.q3tts.causal_conv1d(x, torch.zeros((24, 16, 7)), None, 3, "f32").shape == (2, 50, 24)
+        assert torch.ops.q3tts.causal_trans_conv1d(x, torch.zeros((16, 8, 10)), None, 5, "f32").shape == (2, 245, 8)
+        assert torch.ops.q3tts.snake_beta(x, torch.zeros(16), torch.zeros(16), 1e-9).shape == x.shape
+    with pytest.raises(NotImplementedError):                      # real CPU tensors: there is no CPU kernel
+        torch.ops.q3tts.rvq_dequant(torch.zeros((1, cfg.num_quantizers, 3), dtype=torch.int64), h)
+    torch_ops.unregister_decoder(h)
