@@ -230,6 +230,7 @@ def test_errors():
 def test_torch_custom_ops_run_the_library():
     """torch.ops.q3tts.* are the same entry points behind the dispatcher."""
     from qwen3_tts_amd import torch_ops
+    from qwen3_tts_amd.decoder import Decoder
     cfg = q3.tiny_config("split_rvq")
     w = q3.synthetic_weights(cfg, seed=0)
     dec = Decoder(cfg, w, device="cuda:0", precision="f32")
