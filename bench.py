@@ -117,6 +117,113 @@ def stream_bench(args, cfg, weights, device) -> dict:
             "kernels": [{"kernel": p["kernel"], "launches": p["launches"], "ms_per_step": round(p["ms"], 3)} for p in prof[:8]]}
 
 
+def mixed_bench(args, cfg, weights, device, world, rank, distributed) -> dict:
+    """BASELINE.json configs[3]: `--utterances` utterances of 2-30 s (seeded), bucketed by length, LPT-sharded over the
+    ranks, decoded with no collective, waveforms gathered to rank 0 over RCCL.  Timed end to end, gather included."""
+    import numpy as np
+    import torch.distributed as dist
+    from qwen3_tts_amd.parallel import decode_sharded, lpt_assign
+    rng = np.random.Generator(np.random.PCG64(1234))
+    secs = rng.uniform(2.0, 30.0, size=args.utterances)
+    frames = [int(round(s * cfg.frame_rate)) for s in secs]
+    g = torch.Generator().manual_seed(1234)
+    items = [torch.randint(0, cfg.codebook_size, (cfg.num_quantizers, t), generator=g, dtype=torch.int64) for t in frames]
+    dec = Decoder(cfg, weights, device=device, precision=args.precision, max_frames_per_launch=args.batch * 325)
+    warm = [items[i] for i in range(min(64, len(items)))]
+    dec.decode_device(warm)
+    torch.cuda.synchronize(device)
+    if distributed:
+        dist.barrier()
+    t0 = time.perf_counter()
+    if distributed:
+        out = decode_sharded(dec, items, dst=0)
+        wavs = out[0] if rank == 0 else None
+        torch.cuda.synchronize(device)
+        dist.barrier()
+    else:
+        wavs, _ = dec.decode(items)
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return {}
+    assert len(wavs) == len(items) and all(len(w) == cfg.chunked_output_length(t) for w, t in zip(wavs, frames))
+    audio = sum(frames) / cfg.frame_rate
+    loads = [sum(frames[i] for i in shard) for shard in lpt_assign(frames, world)]
+    return {"metric": "audio-sec decoded/sec", "value": round(audio / elapsed, 1), "unit": "audio-sec/sec", "n_gpus": world,
+            "steps": 1, "warmup": 1, "ms_per_step": round(elapsed * 1e3, 1), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"{len(items)} utterances of 2-30 s (seed 1234), padded to 25-frame buckets, LPT-sharded over "
+                                   f"{world} rank(s), waveforms gathered to rank 0 and copied to host, flagship architecture",
+                       "audio_seconds": round(audio, 1), "rank_load_imbalance": round(max(loads) / (sum(loads) / world), 4)}}
+
+
+def longform_bench(args, cfg, weights, device, world, rank, distributed) -> dict:
+    """BASELINE.json configs[4]: one 10-minute utterance (7500 frames).  (a) the reference's semantics - chunked_decode,
+    25 chunks of 300 + 25 frames - with the chunks batched into one launch sequence per GPU (sharded round-robin when
+    N > 1); (b) on one GPU also the exact variant: the streaming decode advanced 300 frames per push, state carried
+    in HBM, no recomputed context and no seams."""
+    import torch.distributed as dist
+    from qwen3_tts_amd.parallel import decode_long_sharded
+    T = int(round(args.seconds * cfg.frame_rate))
+    codes = q3.random_codes(cfg, 1, T, seed=3).to(device)
+    dec = Decoder(cfg, weights, device=device, precision=args.precision, max_positions=max(8192, T),
+                  max_frames_per_launch=max(args.batch * 325, 26 * 325))
+    expect = cfg.chunked_output_length(T)
+
+    def chunked():
+        if distributed:
+            return decode_long_sharded(dec, codes[0], cfg.chunk_size, cfg.left_context_size, dst=0)
+        return dec.chunked_decode(codes, cfg.chunk_size, cfg.left_context_size)
+
+    def timeit(fn, steps, warmup):
+        for _ in range(warmup):
+            r = fn()
+        torch.cuda.synchronize(device)
+        if distributed:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = fn()
+        torch.cuda.synchronize(device)
+        if distributed:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return r, dt / steps
+
+    wav, dt = timeit(chunked, args.steps, args.warmup)
+    extra = {}
+    if not distributed:
+        assert wav.shape == (1, 1, expect)
+        pool = dec.open_streams(1)
+        ids = torch.zeros(1, dtype=torch.int32, device=device)
+
+        def exact():
+            pool.close_stream(pool.open())            # reset slot 0
+            parts = [pool.push_raw(ids, codes[:, :, a:a + 300]) for a in range(0, T, 300)]
+            return parts
+
+        parts, dte = timeit(exact, args.steps, args.warmup)
+        assert sum(p.shape[1] for p in parts) == T * cfg.total_upsample
+        extra = {"exact_streaming_ms": round(dte * 1e3, 2), "exact_streaming_audio_sec_per_sec": round(T / cfg.frame_rate / dte, 1)}
+    elif rank == 0:
+        assert wav.shape == (expect,)
+    if rank != 0:
+        return {}
+    return {"metric": "audio-sec decoded/sec", "value": round(T / cfg.frame_rate / dt, 1), "unit": "audio-sec/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 2), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"one {args.seconds:g} s utterance ({T} frames), chunked decode 300+25 "
+                                   f"({len(cfg.chunk_plan(T))} chunks batched, round-robin over {world} rank(s)), flagship architecture",
+                       **extra}}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,7 +236,9 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=3, help="utterances in the CPU baseline sample")
     ap.add_argument("--tiny", action="store_true", help="tiny architecture (plumbing check only; not a valid result)")
-    ap.add_argument("--workload", default="bulk", choices=["bulk", "stream"], help="bulk = configs[1] (the headline); stream = configs[2]")
+    ap.add_argument("--workload", default="bulk", choices=["bulk", "stream", "mixed", "longform"],
+                    help="bulk = configs[1] (the headline); stream = configs[2]; mixed = configs[3]; longform = configs[4]")
+    ap.add_argument("--utterances", type=int, default=10000)
     ap.add_argument("--streams", type=int, default=256)
     ap.add_argument("--push-frames", type=int, default=1)
     args = ap.parse_args()
@@ -152,6 +261,17 @@ def main() -> None:
         if distributed:
             raise SystemExit("the streaming workload is measured on one GPU (streams never migrate between GPUs)")
         print(json.dumps(stream_bench(args, cfg, weights, device)), flush=True)
+        return
+    if args.workload in ("mixed", "longform"):
+        if args.workload == "longform" and args.seconds == 30.0:
+            args.seconds = 600.0
+        fn = mixed_bench if args.workload == "mixed" else longform_bench
+        res = fn(args, cfg, weights, device, world, rank, distributed)
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+        if distributed:
+            dist.barrier()
+            dist.destroy_process_group()
         return
     frames = int(round(args.seconds * cfg.frame_rate))
     dec = Decoder(cfg, weights, device=device, precision=args.precision, max_frames_per_launch=args.batch * 325)

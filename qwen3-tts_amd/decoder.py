@@ -200,17 +200,13 @@ class Decoder:
             return items
         return one(encoded)
 
-    def decode(self, encoded: CodesLike, chunk_size: Optional[int] = None, left_context_size: Optional[int] = None,
-               pad_to: int = 25) -> Tuple[List[np.ndarray], int]:
-        """-> (list of float32 1-D numpy waveforms, 24000).  Utterances of different length are decoded together:
-        every (utterance, chunk) piece is padded with code 0 to a multiple of `pad_to` frames, pieces of equal padded
-        length share a launch sequence, and each piece keeps only its own prefix of the output (a frame never
-        influences samples that precede it by more than the fixed 555-sample lookahead)."""
+    def decode_device(self, encoded: CodesLike, chunk_size: Optional[int] = None, left_context_size: Optional[int] = None,
+                      pad_to: int = 25) -> Tuple[torch.Tensor, List[int], List[int]]:
+        """The decode of `decode` without the copy to the host: -> (flat float32 device tensor holding every
+        utterance's samples back to back, start offset per utterance, length per utterance)."""
         cs = self.cfg.chunk_size if chunk_size is None else chunk_size
         lc = self.cfg.left_context_size if left_context_size is None else left_context_size
         items = self._normalize_items(encoded)
-        if not items:
-            return [], self.cfg.sample_rate
         up, Q = self.cfg.total_upsample, self.cfg.num_quantizers
         lengths, starts, jobs = [], [], []      # jobs: (item, s, e, ctx, offset_in_item)
         total = 0
@@ -227,6 +223,8 @@ class Decoder:
                 jobs.append((i, s, e, ctx, off))
                 off += self.cfg.output_length(e - s) - ctx * up
         out = torch.empty(total, dtype=torch.float32, device=self.device)
+        if not items:
+            return out, starts, lengths
         dev_items = [c.to(self.device) for c in items]
         buckets: Dict[int, List[int]] = {}
         for j, (_i, s, e, _ctx, _off) in enumerate(jobs):
@@ -246,6 +244,15 @@ class Decoder:
                     out[starts[i] + off: starts[i] + off + keep] = wav[n, 0, ctx * up: ctx * up + keep]
         with torch.cuda.device(self.device):
             self._check(self._lib.q3c_check_errors(self._ctx, self._stream()))
+        return out, starts, lengths
+
+    def decode(self, encoded: CodesLike, chunk_size: Optional[int] = None, left_context_size: Optional[int] = None,
+               pad_to: int = 25) -> Tuple[List[np.ndarray], int]:
+        """-> (list of float32 1-D numpy waveforms, 24000).  Utterances of different length are decoded together:
+        every (utterance, chunk) piece is padded with code 0 to a multiple of `pad_to` frames, pieces of equal padded
+        length share a launch sequence, and each piece keeps only its own prefix of the output (a frame never
+        influences samples that precede it by more than the fixed 555-sample lookahead)."""
+        out, starts, lengths = self.decode_device(encoded, chunk_size, left_context_size, pad_to)
         host = out.cpu().numpy()
         return [host[s:s + n].copy() for s, n in zip(starts, lengths)], self.cfg.sample_rate
 

@@ -97,8 +97,40 @@ def decode_sharded(decoder, items: Sequence[torch.Tensor], dst: Optional[int] = 
     Q = decoder.cfg.num_quantizers
     lengths = [int(c.shape[0] if c.shape[-1] == Q else c.shape[-1]) for c in items]
     mine = lpt_assign(lengths, world)[rank]
-    wavs, sr = decoder.decode([items[i] for i in mine]) if mine else ([], decoder.cfg.sample_rate)
-    dev = getattr(decoder, "device", torch.device("cpu"))
-    local = [torch.from_numpy(w).to(dev) for w in wavs]
+    sr = decoder.cfg.sample_rate
+    if not mine:
+        local = []
+    elif hasattr(decoder, "decode_device"):          # samples stay on the GPU until the gather
+        flat, starts, lens = decoder.decode_device([items[i] for i in mine])
+        local = [flat[s:s + n] for s, n in zip(starts, lens)]
+    else:
+        wavs, sr = decoder.decode([items[i] for i in mine])
+        local = [torch.from_numpy(w) for w in wavs]
     out = gather_waveforms(local, mine, len(items), dst=dst, group=group)
     return None if out is None else (out, sr)
+
+
+def decode_long_sharded(decoder, codes: torch.Tensor, chunk_size: int = 300, left_context_size: int = 25, dst: Optional[int] = 0,
+                        group=None) -> Optional[torch.Tensor]:
+    """One long utterance, codes [Q, T]: the chunks of chunked_decode are independent (each recomputes its own left
+    context), so chunk c goes to rank c mod world_size; every rank decodes its chunks as one batch and the pieces are
+    gathered in order.  Returns the [samples] waveform (numpy) on the destination rank(s)."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    cfg = decoder.cfg
+    T = int(codes.shape[-1])
+    plan = cfg.chunk_plan(T, chunk_size, left_context_size)
+    mine = chunk_assign(len(plan), world)[rank]
+    up = cfg.total_upsample
+    local: List[torch.Tensor] = []
+    by_len = {}
+    for c in mine:
+        by_len.setdefault(plan[c][1] - plan[c][0], []).append(c)
+    pieces = {}
+    for _length, cs in by_len.items():
+        batch = torch.stack([codes[:, plan[c][0]:plan[c][1]] for c in cs])
+        wav = decoder.forward(batch)
+        for n, c in enumerate(cs):
+            pieces[c] = wav[n, 0, plan[c][2] * up:]
+    local = [pieces[c] for c in mine]
+    out = gather_waveforms(local, mine, len(plan), dst=dst, group=group)
+    return None if out is None else np.concatenate(out)

@@ -110,7 +110,7 @@ import os, sys
 import numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "oracle"))
 import qwen3_tts_amd as q3
-from qwen3_tts_amd.parallel import decode_sharded, gather_waveforms
+from qwen3_tts_amd.parallel import decode_long_sharded, decode_sharded, gather_waveforms
 import decoder_oracle as oracle
 
 rank = int(os.environ["RANK"])
@@ -135,6 +135,23 @@ else:
 everyone = decode_sharded(CpuStandIn(), items, dst=None)
 for a, b in zip(everyone[0], want):
     assert np.array_equal(a, b)
+
+class DeviceStandIn(CpuStandIn):     # the form the GPU decoder offers: samples stay in one flat tensor until the gather
+    def decode_device(self, items):
+        wavs, _ = oracle.decode(cfg, w, [torch.as_tensor(c) for c in items])
+        lens = [len(x) for x in wavs]
+        starts = [int(v) for v in np.cumsum([0] + lens[:-1])]
+        return torch.cat([torch.from_numpy(x) for x in wavs]), starts, lens
+    def forward(self, codes): return oracle.forward(cfg, w, codes)
+out = decode_sharded(DeviceStandIn(), items, dst=None)
+for a, b in zip(out[0], want):
+    assert np.array_equal(a, b)
+# one long utterance: its chunks are sharded round-robin and gathered in order
+long_codes = q3.random_codes(cfg, 1, 23, seed=7)
+want_long = oracle.chunked_decode(cfg, w, long_codes, 5, 2)[0, 0].numpy()
+got_long = decode_long_sharded(DeviceStandIn(), long_codes[0], 5, 2, dst=None)
+assert got_long.shape == want_long.shape == (cfg.chunked_output_length(23, 5, 2),)
+assert np.abs(got_long - want_long).max() <= 1e-4      # fp32 batching noise of the CPU GEMMs is ~2e-5
 # a rank with nothing to send
 local = [torch.arange(5, dtype=torch.float32)] if rank == 1 else []
 got = gather_waveforms(local, [0] if rank == 1 else [], 1, dst=0)
