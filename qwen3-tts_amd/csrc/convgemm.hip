@@ -27,6 +27,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <type_traits>
 
 namespace {
 
@@ -66,6 +67,10 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
         if (n >= 2) { if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
         else { if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     }
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt_c() {
+    static_assert(N >= 0 && N <= 15, "vmcnt immediate");
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
 }
 // One LDS-DMA instruction: 16 bytes per lane from global memory to LDS at lds_addr + lane * 16 (lds_addr wave-uniform).
 // Issued through inline asm on purpose: the compiler then neither counts it nor guards later ds_reads with vmcnt(0), so
@@ -109,18 +114,42 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    // 1-D tile index with the N tiles fastest: blocks that share an input tile are dispatched together
+    // 1-D tile index with the N tiles fastest.  Workgroups are dealt round-robin over the 8 XCDs (each with its own
+    // L2), so workgroup ids congruent mod 8 share an L2: give each such group a CONTIGUOUS run of tiles, so the blocks
+    // that read the same input rows (the N tiles of one M tile) and walk the same weights run side by side on one L2.
     const int n_tiles = (p.N + BN - 1) / BN;
-    const int b = blockIdx.y;
-    const int n0 = (int)(blockIdx.x % n_tiles) * BN;
-    const int m0 = (int)(blockIdx.x / n_tiles) * BM;
+    int b = blockIdx.y;
+    int tile = blockIdx.x;
+    int n0, m0;
+    if (!(p.debug & 16)) {
+        const int wg = blockIdx.y * gridDim.x + blockIdx.x;        // dispatch order: x fastest
+        const int nwg = gridDim.x * gridDim.y, q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
+        const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+        if (!(p.debug & 32)) {
+            // N tile slowest over the WHOLE grid: an XCD's run of tiles walks down the rows of one or two N tiles, so
+            // the weight slices it streams every step (taps x BN x K, re-read by every block) stay in its L2
+            const int m_tiles = gridDim.x / n_tiles, per_n = m_tiles * gridDim.y;
+            const int nt = id / per_n, rest = id - nt * per_n;
+            b = rest / m_tiles;
+            n0 = nt * BN;
+            m0 = (rest - b * m_tiles) * BM;
+        } else {
+            b = id / (int)gridDim.x;
+            tile = id - b * (int)gridDim.x;
+            n0 = (tile % n_tiles) * BN;
+            m0 = (tile / n_tiles) * BM;
+        }
+    } else {
+        n0 = (tile % n_tiles) * BN;
+        m0 = (tile / n_tiles) * BM;
+    }
 
     const int halo = (p.taps - 1) * p.off_step;
     const int HR = BM + halo;                        // staged input rows
     const int xpieces = HR * CPR;
     const int xi_total = (xpieces + NTHR - 1) / NTHR;
     const int xps = (xi_total + p.taps - 1) / p.taps;   // pieces per thread per step (<= MAX_XPS, host-checked)
-    const size_t XBUF = round_kb((size_t)HR * BKB);
+    const size_t XBUF = (size_t)xi_total * NW * 1024;          // whole slices: every wave of every slice has its KiB
     const size_t hs_bytes = (size_t)BM * (p.N * sizeof(TA) + 16);
     const size_t region0 = (FUSE2 && hs_bytes > 2 * XBUF) ? hs_bytes : 2 * XBUF;
 
@@ -184,7 +213,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
     // input rows [it*XROWS_PER_IT ...) of chunk kc -> buffer at xs; rows outside the sequence come from the zero page
     auto x_dma_issue = [&](unsigned xs, int it, int kc) {
         const int slot = it * NW + wave;
-        if (slot * 64 >= xpieces) { dma16_so(zero_page, 0u, spare_lds); return; }
+        if (it >= xi_total) { dma16_so(zero_page, 0u, spare_lds); return; }     // a step with no slice left: padding DMA
         const TA* sbase = xtile + ((long long)it * XROWS_PER_IT * p.ldx + kc * BK);
         if (interior) {
             dma16_so(sbase, xvoff0, xs + (unsigned)slot * 1024u);
@@ -205,12 +234,13 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
         wvoff[q] = (unsigned)((n * p.K + swz<CPR>(row, cs) * EPC) * (int)sizeof(TA));
         w2voff[q] = (unsigned)((n * p.N + swz<CPR>(row, cs) * EPC) * (int)sizeof(TA));
     }
+    auto w_dma_one = [&](unsigned ws, const TA* sbase, const unsigned* voff, int q) {
+        if (WITER * NW * 64 == WPIECES || (q * NW + wave) * 64 < WPIECES) dma16_so(sbase, voff[q], ws + (unsigned)(q * NW + wave) * 1024u);
+        else dma16_so(zero_page, 0u, spare_lds);
+    };
     auto w_dma_issue = [&](unsigned ws, const TA* sbase, const unsigned* voff) {
 #pragma unroll
-        for (int q = 0; q < WITER; ++q) {
-            if ((q * NW + wave) * 64 < WPIECES) dma16_so(sbase, voff[q], ws + (unsigned)(q * NW + wave) * 1024u);
-            else dma16_so(zero_page, 0u, spare_lds);
-        }
+        for (int q = 0; q < WITER; ++q) w_dma_one(ws, sbase, voff, q);
     };
 
     f32x16 acc[WM][WN];
@@ -221,29 +251,37 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // MFMAs of one step: every wave multiplies its rows of the staged input (shifted by the tap) with the weight tile
-    auto compute = [&](const unsigned char* xs, const unsigned char* ws, int row_shift) {
+    // MFMAs of one step: every wave multiplies its rows of the staged input (shifted by the tap) with the weight tile.
+    // The fragments of group kg + 1 are read from LDS before the MFMAs of group kg issue, so a wave's LDS latency hides
+    // under its own matrix work.  `between(kg)` runs ahead of group kg: the pipeline issues its LDS-DMAs there, spread
+    // over the groups, so the address unit works through them while the matrix cores run.
+    auto compute = [&](const unsigned char* xs, const unsigned char* ws, int row_shift, auto&& between) {
         const int arow0 = wm * 32 * WM + (lane & 31) + row_shift;
         const int brow0 = wn * 32 * WN + (lane & 31);
-#pragma unroll
-        for (int kg = 0; kg < KG; ++kg) {
+        uint4 af[2][WM], bfr[2][WN];
+        auto load = [&](int buf, int kg) {
             const int c = kg * 2 + (lane >> 5);
-            uint4 af[WM], bfr[WN];
 #pragma unroll
             for (int i = 0; i < WM; ++i) {
                 int row = arow0 + i * 32;
-                af[i] = *(const uint4*)(xs + (size_t)row * BKB + swz<CPR>(row, c) * 16);
+                af[buf][i] = *(const uint4*)(xs + (size_t)row * BKB + swz<CPR>(row, c) * 16);
             }
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
                 int row = brow0 + j * 32;
-                bfr[j] = *(const uint4*)(ws + (size_t)row * BKB + swz<CPR>(row, c) * 16);
+                bfr[buf][j] = *(const uint4*)(ws + (size_t)row * BKB + swz<CPR>(row, c) * 16);
             }
+        };
+        load(0, 0);
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) {
+            between(kg);
+            if (kg + 1 < KG) load((kg + 1) & 1, kg + 1);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < WN; ++j) Mma<TA>::run(af[i], bfr[j], acc[i][j]);
+                for (int j = 0; j < WN; ++j) Mma<TA>::run(af[kg & 1][i], bfr[kg & 1][j], acc[i][j]);
             __builtin_amdgcn_s_setprio(0);
         }
     };
@@ -251,8 +289,10 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
     if (dma) {
         // ---- LDS-DMA pipeline: weight tiles two steps ahead in three buffers, the next chunk's input tile in slices
         //      spread over this chunk's steps; each step waits with vmcnt(n) for all but the DMAs that may stay in
-        //      flight, then one raw barrier.
+        //      flight, then one raw barrier.  The slice count per step is a compile-time constant of the loop (one
+        //      instantiation per value) so that the steady-state waits are immediates and the slice loop unrolls.
         const long long tap_stride = (long long)p.N * p.K;       // elements between taps of W
+        const long long slice_stride = (long long)XROWS_PER_IT * p.ldx;   // elements between input slices
         for (int it = 0; it < xi_total; ++it) x_dma_issue(xs_lds, it, 0);
         w_dma_issue(ws_lds, Wg, wvoff);
         if (nsteps > 1) {
@@ -262,25 +302,81 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
             wait_vmcnt(0);
         }
         block_barrier();
-        int kc = 0, tap = 0, wb = 0;                             // wb: weight buffer of the current step
+        // pipeline state, shared by the two loops below
+        int step = 0, kc = 0, tap = 0, wb = 0;                   // wb: weight buffer of the current step
         int ltap = p.taps > 2 ? 2 : 0, lkc = p.taps > 2 ? 0 : (p.taps == 2 ? 1 : 2);   // (tap, chunk) of step + 2
-        for (int step = 0; step < nsteps; ++step) {
-            const int wb1 = wb == 2 ? 0 : wb + 1, wb2 = wb1 == 2 ? 0 : wb1 + 1;
-            const bool more_x = (kc + 1) < nkc, more_w = (step + 2) < nsteps;
-            if (more_x) {
-                const unsigned xsn = xs_lds + (unsigned)(((kc + 1) & 1) * XBUF);
-#pragma unroll 1
-                for (int i = 0; i < xps; ++i) x_dma_issue(xsn, tap * xps + i, kc + 1);
+        const TA* wsrc = Wg + (ltap * tap_stride + (long long)lkc * BK);               // weight tile of step + 2
+        const TA* xsrc = xtile + BK;                             // slice `xit` of the next chunk (interior tiles)
+        int xit = 0;
+        auto advance = [&](bool boundary, int xps_c) {
+            if (boundary) { tap = 0; ++kc; xit = 0; xsrc = xtile + (long long)(kc + 1) * BK; }
+            else { ++tap; xit += xps_c; xsrc += xps_c * slice_stride; }
+            wsrc += tap_stride;
+            if (++ltap == p.taps) { ltap = 0; ++lkc; wsrc += (long long)BK - p.taps * tap_stride; }
+            wb = wb == 2 ? 0 : wb + 1;
+        };
+        // Steady state of an interior tile (every staged row inside the sequence, a next chunk and a weight tile two
+        // steps on still to fetch): no per-lane or per-step conditions, immediates for the waits.  Issue slots are the
+        // scarce resource next to the matrix pipe - every instruction a wave issues here adds to the step's time.
+        auto lean = [&](auto xps_tag, int lean_steps) {
+            constexpr int XPS = decltype(xps_tag)::value;
+            const unsigned xdst_w = xs_lds + (unsigned)wave * 1024u, wdst_w = ws_lds + (unsigned)wave * 1024u;
+            for (; step < lean_steps; ++step) {
+                const unsigned xsn = xdst_w + (unsigned)(((kc + 1) & 1) * XBUF);
+                const unsigned wsn = wdst_w + (unsigned)((wb == 0 ? 2 : wb - 1) * WBUF);
+                compute(Xs0 + (size_t)(kc & 1) * XBUF, Ws0 + (size_t)wb * WBUF, tap * p.off_step, [&](int kg) {
+                    if (kg == 0) {
+#pragma unroll
+                        for (int i = 0; i < XPS; ++i) {
+                            if (xit + i < xi_total) dma16_so(xsrc + i * slice_stride, xvoff0, xsn + (unsigned)((xit + i) * NW) * 1024u);
+                            else dma16_so(zero_page, 0u, spare_lds);
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < WITER; ++q)
+                        if ((q + 1 < KG ? q + 1 : KG - 1) == kg) {
+                            if (WITER * NW * 64 == WPIECES || (q * NW + wave) * 64 < WPIECES) dma16_so(wsrc, wvoff[q], wsn + (unsigned)(q * NW) * 1024u);
+                            else dma16_so(zero_page, 0u, spare_lds);
+                        }
+                });
+                const bool boundary = (tap + 1) == p.taps;
+                if (boundary) wait_vmcnt_c<WITER>(); else wait_vmcnt_c<WITER + XPS>();
+                block_barrier();
+                advance(boundary, XPS);
             }
-            if (more_w) w_dma_issue(ws_lds + (unsigned)(wb2 * WBUF), Wg + (ltap * tap_stride + (long long)lkc * BK), wvoff);
-            if (!(p.debug & 2)) compute(Xs0 + (size_t)(kc & 1) * XBUF, Ws0 + (size_t)wb * WBUF, tap * p.off_step);
-            // the next step needs weight tile step+1 (issued a step ago) and, when it opens a new chunk, every input slice
-            const bool boundary = (tap + 1) == p.taps;
-            wait_vmcnt((more_w ? WITER : 0) + ((more_x && !boundary) ? xps : 0));
-            block_barrier();
-            if (++tap == p.taps) { tap = 0; ++kc; }
-            if (++ltap == p.taps) { ltap = 0; ++lkc; }
-            wb = wb1;
+        };
+        auto pipeline = [&](auto xps_tag) {
+            constexpr int XPS = decltype(xps_tag)::value;
+            for (; step < nsteps; ++step) {
+                const int wb2 = wb == 0 ? 2 : wb - 1;
+                const bool more_x = (kc + 1) < nkc, more_w = (step + 2) < nsteps;
+                const unsigned xsn = xs_lds + (unsigned)(((kc + 1) & 1) * XBUF);
+                const unsigned wsn = ws_lds + (unsigned)(wb2 * WBUF);
+                // this step's DMAs, oldest first: the next chunk's input slices (group 0), then the weight tile of step + 2
+                compute(Xs0 + (size_t)(kc & 1) * XBUF, Ws0 + (size_t)wb * WBUF, tap * p.off_step, [&](int kg) {
+                    if (kg == 0 && more_x) {
+#pragma unroll 1
+                        for (int i = 0; i < XPS; ++i) x_dma_issue(xsn, xit + i, kc + 1);
+                    }
+                    if (more_w) {
+#pragma unroll
+                        for (int q = 0; q < WITER; ++q)
+                            if ((q + 1 < KG ? q + 1 : KG - 1) == kg) w_dma_one(wsn, wsrc, wvoff, q);
+                    }
+                });
+                // the next step needs weight tile step+1 (issued a step ago) and, when it opens a new chunk, every input slice
+                const bool boundary = (tap + 1) == p.taps;
+                wait_vmcnt((more_w ? WITER : 0) + ((more_x && !boundary) ? XPS : 0));
+                block_barrier();
+                advance(boundary, XPS);
+            }
+        };
+        const int lean_steps = (interior && nkc >= 2) ? ((nkc - 1) * p.taps < nsteps - 2 ? (nkc - 1) * p.taps : nsteps - 2) : 0;
+        switch (xps) {
+            case 1: lean(std::integral_constant<int, 1>{}, lean_steps); pipeline(std::integral_constant<int, 1>{}); break;
+            case 2: lean(std::integral_constant<int, 2>{}, lean_steps); pipeline(std::integral_constant<int, 2>{}); break;
+            case 3: lean(std::integral_constant<int, 3>{}, lean_steps); pipeline(std::integral_constant<int, 3>{}); break;
+            default: lean(std::integral_constant<int, 4>{}, lean_steps); pipeline(std::integral_constant<int, 4>{}); break;
         }
     } else {
         // ---- K tail (narrow test shapes): synchronous register staging, zero-filled past K ----
@@ -291,7 +387,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
 #pragma unroll
             for (int it = 0; it < WITER; ++it) w_store(Ws0, tid + it * NTHR, w_load(Wg, p.K, tid + it * NTHR, kc, tap));
             __syncthreads();
-            compute(Xs0, Ws0, tap * p.off_step);
+            compute(Xs0, Ws0, tap * p.off_step, [](int) {});
             __syncthreads();
             if (++tap == p.taps) { tap = 0; ++kc; }
         }
@@ -300,7 +396,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
     const int half = lane >> 5, l31 = lane & 31;
 
     // ---- fused second contraction (k = 1): h = snake(acc + bias) -> LDS -> acc = h . W2^T -------------------------
-    if (FUSE2 && !(p.debug & 4)) {
+    if (FUSE2) {
         const int HLD = p.N * (int)sizeof(TA) + 16;                 // padded row stride of the h tile
         unsigned char* Hs = smem;                                   // overlays the (now idle) input buffers
         const TA* __restrict__ W2 = (const TA*)p.W2;
@@ -386,7 +482,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
     TO* __restrict__ Y2b = p.Y2 ? (TO*)p.Y2 + (long long)b * p.y2_batch_stride : nullptr;
     const TO* __restrict__ Rb = p.R ? (const TO*)p.R + (long long)b * p.r_batch_stride : nullptr;
     constexpr int EPO = 16 / (int)sizeof(TO);            // output elements per 16-byte piece
-    constexpr int JG = WN < 3 ? WN : 3;                   // column tiles per slab pass
+    constexpr int JG = WN <= 4 ? WN : 3;                  // column tiles per slab pass
     constexpr int SCOLS = 32 * JG;
     constexpr int SLD = SCOLS + 4;                        // slab row stride in floats (keeps rows 16-byte aligned)
     constexpr int SROWS = 16;
@@ -420,7 +516,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
             for (int rh = 0; rh < 2; ++rh) {                            // rows 0-15, then 16-31 of the 32-row tile
                 const int mrow0 = m0 + wm * 32 * WM + i * 32 + rh * 16;
                 // phase 0: residual -> slab A
-                if (Rb && !(p.debug & 1)) {
+                if (Rb) {
                     for (int id = lane; id < SROWS * cprw; id += 64) {
                         const int row = id / cprw, ch = id - row * cprw;
                         const int m = mrow0 + row, n = ncol0 + ch * EPO;
@@ -448,8 +544,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
                     __builtin_amdgcn_wave_barrier();
                 }
                 // phase 1: column-wise math
-                if (p.debug & 8) {
-                } else if (swiglu) {
+                if (swiglu) {
                     if constexpr (JG % 2 == 0) {
 #pragma unroll
                         for (int j = 0; j < JG; j += 2) {
@@ -498,7 +593,6 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
                 }
                 __builtin_amdgcn_wave_barrier();
                 // phase 2: slabs -> memory, 16 bytes per lane
-                if (!(p.debug & 1))
                 for (int id = lane; id < SROWS * cprw; id += 64) {
                     const int row = id / cprw, ch = id - row * cprw;
                     const int m = mrow0 + row, n = ncol0 + ch * EPO;
@@ -545,14 +639,14 @@ hipError_t launch_cfg(const ConvGemmArgs& a, hipStream_t s) {
     constexpr int NW = WAVES_M * WAVES_N, NTHR = 64 * NW;
     constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
     constexpr int CPR = BKB / 16;
-    constexpr int JG = WN < 3 ? WN : 3;
+    constexpr int JG = WN <= 4 ? WN : 3;
     const int halo = (a.taps - 1) * a.off_step;
     const int HR = BM + halo;
     const int xi_total = (HR * CPR + NTHR - 1) / NTHR;
     const int xps = (xi_total + a.taps - 1) / a.taps;
-    if (xps > (BM * CPR + NTHR - 1) / NTHR) return hipErrorInvalidValue;      // halo too large for the staged-slice scheme
+    if (xps > (BM * CPR + NTHR - 1) / NTHR || xps > 4) return hipErrorInvalidValue;      // halo too large for the staged-slice scheme
     if (FUSE2 && (a.N > BN || !a.W2 || a.act == Q3_ACT_SWIGLU)) return hipErrorInvalidValue;
-    size_t region0 = 2 * round_kb((size_t)HR * BKB);
+    size_t region0 = 2 * (size_t)xi_total * NW * 1024;
     if (FUSE2) region0 = std::max(region0, (size_t)BM * (a.N * sizeof(TA) + 16));
     size_t lds = round_kb(region0) + 3 * round_kb((size_t)BN * BKB) + 1024;       // + a spare KiB for padding DMAs
     lds = std::max(lds, (size_t)NW * 2 * 16 * (32 * JG + 4) * sizeof(float));    // two wave-private 16-row epilogue slabs per wave
@@ -573,7 +667,8 @@ hipError_t launch_cfg(const ConvGemmArgs& a, hipStream_t s) {
 }
 
 // tile shapes (rows x columns, K-row bytes, waves)
-enum { SH_256x96 = 0, SH_256x128_K128, SH_128x128_K128, SH_128x128_K64, SH_256x32, SH_F_256x192, SH_F_256x96, SH_F_256x32, SH_COUNT };
+enum { SH_256x96 = 0, SH_256x128_K128, SH_128x128_K128, SH_128x128_K64, SH_256x32, SH_F_256x192, SH_F_256x96, SH_F_256x32,
+       SH_256x256_K64, SH_256x192_K64, SH_COUNT };
 
 int pick_shape(const ConvGemmArgs& a, size_t elem) {
     if (a.W2) {                                   // fused residual unit: one N tile must hold every channel
@@ -587,6 +682,10 @@ int pick_shape(const ConvGemmArgs& a, size_t elem) {
     const bool use_96 = (a.act != Q3_ACT_SWIGLU) && (a.N % 128 != 0) && (a.N % 96 == 0) && a.N < 512;
     if (use_96) return SH_256x96;
     if (!wide_k) return SH_128x128_K64;
+    if (!(g_tuning & 2) && a.act != Q3_ACT_SWIGLU && (long long)a.B * a.M >= 8192) {     // enough rows to fill the chip with big tiles
+        if (a.N % 256 == 0) return SH_256x256_K64;
+        if (a.N % 192 == 0) return SH_256x192_K64;
+    }
     return (g_tuning & 1) ? SH_128x128_K128 : SH_256x128_K128;
 }
 
@@ -598,6 +697,8 @@ hipError_t launch_typed(const ConvGemmArgs& a, hipStream_t s) {
         case SH_128x128_K128: return launch_cfg<TA, TO, 2, 2, 2, 2, 128, false>(a, s);
         case SH_128x128_K64: return launch_cfg<TA, TO, 2, 2, 2, 2, 64, false>(a, s);
         case SH_256x32: return launch_cfg<TA, TO, 4, 1, 2, 1, 64, false>(a, s);
+        case SH_256x256_K64: return launch_cfg<TA, TO, 4, 2, 2, 4, 64, false>(a, s);
+        case SH_256x192_K64: return launch_cfg<TA, TO, 4, 2, 2, 3, 64, false>(a, s);
         default: break;
     }
     if constexpr (ALLOW_FUSE) {      // the fused form re-reads its input's element type as the residual: same-type pairs only
@@ -620,7 +721,8 @@ extern "C" void q3c_debug_set_tuning(int bits) { g_tuning = bits; }   // measure
 
 const char* q3_convgemm_variant(const ConvGemmArgs& a, int in_dtype, int out_dtype) {
     static const char* shapes[SH_COUNT] = {"256x96,k64B,4w", "256x128,k128B,8w", "128x128,k128B,4w", "128x128,k64B,4w", "256x32,k64B,4w",
-                                           "resunit 256x192,k64B,8w", "resunit 256x96,k64B,4w", "resunit 256x32,k64B,4w"};
+                                           "resunit 256x192,k64B,8w", "resunit 256x96,k64B,4w", "resunit 256x32,k64B,4w",
+                                           "256x256,k64B,8w", "256x192,k64B,8w"};
     static const char* types[4] = {"f32,f32", "bf16,bf16", "f32,bf16", "bf16,f32"};
     static char names[4][SH_COUNT][64];
     const int t = (in_dtype == Q3_F32 && out_dtype == Q3_F32) ? 0 : (in_dtype == Q3_BF16 ? (out_dtype == Q3_BF16 ? 1 : 3) : 2);
