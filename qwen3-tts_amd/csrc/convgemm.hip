@@ -58,10 +58,10 @@ template <> struct Mma<float> {
 __host__ __device__ constexpr size_t round_kb(size_t v) { return (v + 1023) / 1024 * 1024; }
 
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n: all but the n youngest vector-memory operations are done.
-// n above 7 drains instead (always safe: it only waits longer).
+// n above 7 waits for vmcnt(7) (always safe: it only waits longer).
 __device__ __forceinline__ void wait_vmcnt(int n) {
     if (n >= 4) {
-        if (n >= 6) { if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else if (n == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        if (n >= 6) { if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); }
         else { if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
     } else {
         if (n >= 2) { if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
@@ -79,9 +79,11 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_c() {
 //   dma16    : every lane supplies a full 64-bit address
 //   dma16_so : wave-uniform 64-bit base (SGPR pair) + unsigned 32-bit per-lane byte offset
 __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_addr) {
+    lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);      // wave-uniform by construction; pins it to an SGPR
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(lds_addr) : "memory");
 }
 __device__ __forceinline__ void dma16_so(const void* sbase, unsigned voff, unsigned lds_addr) {
+    lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
 }
 __device__ __forceinline__ unsigned lds_address(const void* generic_ptr_into_lds) {
@@ -125,9 +127,11 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
         const int wg = blockIdx.y * gridDim.x + blockIdx.x;        // dispatch order: x fastest
         const int nwg = gridDim.x * gridDim.y, q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
         const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
-        if (!(p.debug & 32)) {
-            // N tile slowest over the WHOLE grid: an XCD's run of tiles walks down the rows of one or two N tiles, so
-            // the weight slices it streams every step (taps x BN x K, re-read by every block) stay in its L2
+        // Which operand is worth keeping in the XCD's L2 decides the order inside its run of tiles.  Multi-tap layers
+        // re-stream taps x BN x K of weights per block: N tile slowest over the WHOLE grid, so the run walks down the
+        // rows of one or two N tiles.  Single-tap layers have small weights and an input tile as large as the output:
+        // N tile fastest, so the blocks sharing an input tile run side by side and it comes from HBM once.
+        if ((p.taps > 1) != ((p.debug & 32) != 0)) {
             const int m_tiles = gridDim.x / n_tiles, per_n = m_tiles * gridDim.y;
             const int nt = id / per_n, rest = id - nt * per_n;
             b = rest / m_tiles;
@@ -151,9 +155,13 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
     const int xps = (xi_total + p.taps - 1) / p.taps;   // pieces per thread per step (<= MAX_XPS, host-checked)
     const size_t XBUF = (size_t)xi_total * NW * 1024;          // whole slices: every wave of every slice has its KiB
     const size_t hs_bytes = (size_t)BM * (p.N * sizeof(TA) + 16);
-    const size_t region0 = (FUSE2 && hs_bytes > 2 * XBUF) ? hs_bytes : 2 * XBUF;
+    // single-tap layers (k = 1 convs, linears) use a fresh input tile every step: three buffers, fetched two steps
+    // ahead like the weights; multi-tap layers keep a tile for `taps` steps: two buffers, the next one filled in slices
+    // layers of two or three taps also get three (when they fit): their chunks are too short to hide an HBM fetch
+    const int nxb = p.nxb;
+    const size_t region0 = (FUSE2 && hs_bytes > nxb * XBUF) ? hs_bytes : nxb * XBUF;
 
-    unsigned char* Xs0 = smem;                       // two input buffers
+    unsigned char* Xs0 = smem;                       // the input buffers
     unsigned char* Ws0 = smem + round_kb(region0);   // three weight buffers
 
     const TA* __restrict__ Xb = (const TA*)p.X + (long long)b * p.x_batch_stride;
@@ -293,23 +301,29 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
         //      instantiation per value) so that the steady-state waits are immediates and the slice loop unrolls.
         const long long tap_stride = (long long)p.N * p.K;       // elements between taps of W
         const long long slice_stride = (long long)XROWS_PER_IT * p.ldx;   // elements between input slices
+        // single-tap steady state needs at least one step with a tile two steps on
+        const bool lean1 = p.taps == 1 && nxb == 3 && interior && nsteps >= 3;
+        const bool lean2 = p.taps > 1 && nxb == 3 && interior && nkc >= 3;       // multi-tap, input tiles two chunks ahead
+        const int x_ahead = lean2 ? 2 : 1;
         for (int it = 0; it < xi_total; ++it) x_dma_issue(xs_lds, it, 0);
         w_dma_issue(ws_lds, Wg, wvoff);
         if (nsteps > 1) {
             w_dma_issue(ws_lds + (unsigned)WBUF, Wg + (p.taps > 1 ? tap_stride : (long long)BK), wvoff);
-            wait_vmcnt(WITER);
+            if (lean1 || lean2) for (int it = 0; it < xi_total; ++it) x_dma_issue(xs_lds + (unsigned)XBUF, it, 1);
+            wait_vmcnt(WITER + ((lean1 || lean2) ? xi_total : 0));
         } else {
             wait_vmcnt(0);
         }
         block_barrier();
-        // pipeline state, shared by the two loops below
-        int step = 0, kc = 0, tap = 0, wb = 0;                   // wb: weight buffer of the current step
+        // pipeline state, shared by the loops below
+        int step = 0, kc = 0, tap = 0, wb = 0, xb = 0;           // wb / xb: weight / input buffer of the current step
+        int x_issued = (lean1 || lean2) ? 1 : 0;                 // highest chunk whose input tile has been requested
         int ltap = p.taps > 2 ? 2 : 0, lkc = p.taps > 2 ? 0 : (p.taps == 2 ? 1 : 2);   // (tap, chunk) of step + 2
         const TA* wsrc = Wg + (ltap * tap_stride + (long long)lkc * BK);               // weight tile of step + 2
-        const TA* xsrc = xtile + BK;                             // slice `xit` of the next chunk (interior tiles)
+        const TA* xsrc = xtile + (long long)x_ahead * BK;        // slice `xit` of the chunk being fetched (interior tiles)
         int xit = 0;
         auto advance = [&](bool boundary, int xps_c) {
-            if (boundary) { tap = 0; ++kc; xit = 0; xsrc = xtile + (long long)(kc + 1) * BK; }
+            if (boundary) { tap = 0; ++kc; xit = 0; xsrc = xtile + (long long)(kc + x_ahead) * BK; xb = xb + 1 == nxb ? 0 : xb + 1; }
             else { ++tap; xit += xps_c; xsrc += xps_c * slice_stride; }
             wsrc += tap_stride;
             if (++ltap == p.taps) { ltap = 0; ++lkc; wsrc += (long long)BK - p.taps * tap_stride; }
@@ -321,62 +335,107 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
         auto lean = [&](auto xps_tag, int lean_steps) {
             constexpr int XPS = decltype(xps_tag)::value;
             const unsigned xdst_w = xs_lds + (unsigned)wave * 1024u, wdst_w = ws_lds + (unsigned)wave * 1024u;
+            // steps between the request of a chunk's last real slice and the chunk's first use (two chunks ahead: plenty)
+            const int slack = lean2 ? 2 : p.taps - (xi_total + XPS - 1) / XPS;
             for (; step < lean_steps; ++step) {
-                const unsigned xsn = xdst_w + (unsigned)(((kc + 1) & 1) * XBUF);
+                const unsigned xsn = xdst_w + (unsigned)((lean2 ? (xb == 0 ? 2 : xb - 1) : (xb ^ 1)) * XBUF);
                 const unsigned wsn = wdst_w + (unsigned)((wb == 0 ? 2 : wb - 1) * WBUF);
-                compute(Xs0 + (size_t)(kc & 1) * XBUF, Ws0 + (size_t)wb * WBUF, tap * p.off_step, [&](int kg) {
-                    if (kg == 0) {
+                // this step's DMAs, oldest first: the weight tile of step + 2 (groups 0..), then the next chunk's input slices
+                // (last group).  Loads retire in order, so a weight tile can only be waited for together with everything
+                // issued before it: the slices, which come from HBM and take longest, go last and get a whole extra step.
+                compute(Xs0 + (size_t)xb * XBUF, Ws0 + (size_t)wb * WBUF, tap * p.off_step, [&](int kg) {
+#pragma unroll
+                    for (int q = 0; q < WITER; ++q)
+                        if ((q < KG ? q : KG - 1) == kg) {
+                            if (WITER * NW * 64 == WPIECES || (q * NW + wave) * 64 < WPIECES) dma16_so(wsrc, wvoff[q], wsn + (unsigned)(q * NW) * 1024u);
+                            else dma16_so(zero_page, 0u, spare_lds);
+                        }
+                    if (kg == KG - 1) {
 #pragma unroll
                         for (int i = 0; i < XPS; ++i) {
                             if (xit + i < xi_total) dma16_so(xsrc + i * slice_stride, xvoff0, xsn + (unsigned)((xit + i) * NW) * 1024u);
                             else dma16_so(zero_page, 0u, spare_lds);
                         }
                     }
-#pragma unroll
-                    for (int q = 0; q < WITER; ++q)
-                        if ((q + 1 < KG ? q + 1 : KG - 1) == kg) {
-                            if (WITER * NW * 64 == WPIECES || (q * NW + wave) * 64 < WPIECES) dma16_so(wsrc, wvoff[q], wsn + (unsigned)(q * NW) * 1024u);
-                            else dma16_so(zero_page, 0u, spare_lds);
-                        }
                 });
+                // The next step reads weight tile step + 1, issued a step ago and followed since by that step's slices,
+                // this step's weight tile and this step's slices: those may stay in flight.  A step that closes a chunk
+                // also needs the chunk's last real slice; when the slices ran out two or more steps ago that is implied.
                 const bool boundary = (tap + 1) == p.taps;
-                if (boundary) wait_vmcnt_c<WITER>(); else wait_vmcnt_c<WITER + XPS>();
+                if (step == 0) wait_vmcnt(WITER + XPS);
+                else if (boundary && slack < 2) wait_vmcnt(slack == 1 ? WITER + XPS : 0);
+                else wait_vmcnt_c<WITER + 2 * XPS>();
                 block_barrier();
                 advance(boundary, XPS);
             }
+            x_issued = kc + x_ahead - 1;    // the general loop requests chunk kc + 1 itself when it is not among these
+        };
+        // Single-tap steady state: input tile AND weight tile of step + 2 requested every step, three buffers each.
+        auto lean_single = [&](auto xps_tag, int lean_steps) {
+            constexpr int XPS = decltype(xps_tag)::value;            // == xi_total: the whole tile every step
+            const unsigned xdst_w = xs_lds + (unsigned)wave * 1024u, wdst_w = ws_lds + (unsigned)wave * 1024u;
+            const TA* xsrc2 = xtile + 2 * BK;                        // input tile of step + 2
+            for (; step < lean_steps; ++step) {
+                const unsigned xsn = xdst_w + (unsigned)((xb == 0 ? 2 : xb - 1) * XBUF);
+                const unsigned wsn = wdst_w + (unsigned)((wb == 0 ? 2 : wb - 1) * WBUF);
+                compute(Xs0 + (size_t)xb * XBUF, Ws0 + (size_t)wb * WBUF, 0, [&](int kg) {
+#pragma unroll
+                    for (int q = 0; q < WITER; ++q)
+                        if ((q < KG ? q : KG - 1) == kg) {
+                            if (WITER * NW * 64 == WPIECES || (q * NW + wave) * 64 < WPIECES) dma16_so(wsrc, wvoff[q], wsn + (unsigned)(q * NW) * 1024u);
+                            else dma16_so(zero_page, 0u, spare_lds);
+                        }
+                    // the tile's slices spread over the later groups
+#pragma unroll
+                    for (int i = 0; i < XPS; ++i)
+                        if ((KG - 1 - (XPS - 1 - i) * (KG - 1) / (XPS > 1 ? XPS - 1 : 1)) == kg)
+                            dma16_so(xsrc2 + i * slice_stride, xvoff0, xsn + (unsigned)(i * NW) * 1024u);
+                });
+                wait_vmcnt_c<WITER + XPS>();       // all but this step's requests: tiles of step + 1 are in
+                block_barrier();
+                xsrc2 += BK;
+                advance(true, XPS);
+            }
+            x_issued = nkc - 1;
         };
         auto pipeline = [&](auto xps_tag) {
             constexpr int XPS = decltype(xps_tag)::value;
             for (; step < nsteps; ++step) {
                 const int wb2 = wb == 0 ? 2 : wb - 1;
-                const bool more_x = (kc + 1) < nkc, more_w = (step + 2) < nsteps;
-                const unsigned xsn = xs_lds + (unsigned)(((kc + 1) & 1) * XBUF);
+                const bool more_x = (kc + 1) < nkc && (kc + 1) > x_issued, more_w = (step + 2) < nsteps;
+                const unsigned xsn = xs_lds + (unsigned)((xb + 1 == nxb ? 0 : xb + 1) * XBUF);
                 const unsigned wsn = ws_lds + (unsigned)(wb2 * WBUF);
-                // this step's DMAs, oldest first: the next chunk's input slices (group 0), then the weight tile of step + 2
-                compute(Xs0 + (size_t)(kc & 1) * XBUF, Ws0 + (size_t)wb * WBUF, tap * p.off_step, [&](int kg) {
-                    if (kg == 0 && more_x) {
-#pragma unroll 1
-                        for (int i = 0; i < XPS; ++i) x_dma_issue(xsn, xit + i, kc + 1);
-                    }
+                // same issue order as the steady-state loop; the waits let only THIS step's DMAs stay in flight, which is
+                // right whatever the steps before left outstanding
+                compute(Xs0 + (size_t)xb * XBUF, Ws0 + (size_t)wb * WBUF, tap * p.off_step, [&](int kg) {
                     if (more_w) {
 #pragma unroll
                         for (int q = 0; q < WITER; ++q)
-                            if ((q + 1 < KG ? q + 1 : KG - 1) == kg) w_dma_one(wsn, wsrc, wvoff, q);
+                            if ((q < KG ? q : KG - 1) == kg) w_dma_one(wsn, wsrc, wvoff, q);
+                    }
+                    if (kg == KG - 1 && more_x) {
+#pragma unroll 1
+                        for (int i = 0; i < XPS; ++i) x_dma_issue(xsn, xit + i, kc + 1);
                     }
                 });
-                // the next step needs weight tile step+1 (issued a step ago) and, when it opens a new chunk, every input slice
                 const bool boundary = (tap + 1) == p.taps;
-                wait_vmcnt((more_w ? WITER : 0) + ((more_x && !boundary) ? XPS : 0));
+                if (boundary) wait_vmcnt(more_x ? 0 : (more_w ? WITER : 0));
+                else wait_vmcnt((more_w ? WITER : 0) + (more_x ? XPS : 0));
                 block_barrier();
                 advance(boundary, XPS);
             }
         };
-        const int lean_steps = (interior && nkc >= 2) ? ((nkc - 1) * p.taps < nsteps - 2 ? (nkc - 1) * p.taps : nsteps - 2) : 0;
+        const int lean_steps = lean1 ? nsteps - 2 : lean2 ? (nkc - 2) * p.taps
+                             : (interior && nkc >= 2 && p.taps >= 2 && nxb == 2) ? (nkc - 1) * p.taps : 0;
+        auto run = [&](auto tag) {
+            if (lean1) lean_single(tag, lean_steps); else lean(tag, lean_steps);
+            pipeline(tag);
+        };
         switch (xps) {
-            case 1: lean(std::integral_constant<int, 1>{}, lean_steps); pipeline(std::integral_constant<int, 1>{}); break;
-            case 2: lean(std::integral_constant<int, 2>{}, lean_steps); pipeline(std::integral_constant<int, 2>{}); break;
-            case 3: lean(std::integral_constant<int, 3>{}, lean_steps); pipeline(std::integral_constant<int, 3>{}); break;
-            default: lean(std::integral_constant<int, 4>{}, lean_steps); pipeline(std::integral_constant<int, 4>{}); break;
+            case 1: run(std::integral_constant<int, 1>{}); break;
+            case 2: run(std::integral_constant<int, 2>{}); break;
+            case 3: run(std::integral_constant<int, 3>{}); break;
+            default: run(std::integral_constant<int, 4>{}); break;
         }
     } else {
         // ---- K tail (narrow test shapes): synchronous register staging, zero-filled past K ----
@@ -635,20 +694,23 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
 int g_tuning = 0;     // bit 0: 4-wave 128x128 tiles instead of 8-wave 256x128 for the wide layers
 
 template <typename TA, typename TO, int WAVES_M, int WAVES_N, int WM, int WN, int BKB, bool FUSE2>
-hipError_t launch_cfg(const ConvGemmArgs& a, hipStream_t s) {
+hipError_t launch_cfg(const ConvGemmArgs& a_in, hipStream_t s) {
     constexpr int NW = WAVES_M * WAVES_N, NTHR = 64 * NW;
     constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
     constexpr int CPR = BKB / 16;
     constexpr int JG = WN <= 4 ? WN : 3;
+    ConvGemmArgs a = a_in;
     const int halo = (a.taps - 1) * a.off_step;
     const int HR = BM + halo;
     const int xi_total = (HR * CPR + NTHR - 1) / NTHR;
     const int xps = (xi_total + a.taps - 1) / a.taps;
     if (xps > (BM * CPR + NTHR - 1) / NTHR || xps > 4) return hipErrorInvalidValue;      // halo too large for the staged-slice scheme
     if (FUSE2 && (a.N > BN || !a.W2 || a.act == Q3_ACT_SWIGLU)) return hipErrorInvalidValue;
-    size_t region0 = 2 * (size_t)xi_total * NW * 1024;
+    const size_t xbuf = (size_t)xi_total * NW * 1024, wring = 3 * round_kb((size_t)BN * BKB) + 1024;   // + a spare KiB for padding DMAs
+    a.nxb = (a.taps <= 3 && round_kb(3 * xbuf) + wring <= 160 * 1024) ? 3 : 2;
+    size_t region0 = a.nxb * xbuf;
     if (FUSE2) region0 = std::max(region0, (size_t)BM * (a.N * sizeof(TA) + 16));
-    size_t lds = round_kb(region0) + 3 * round_kb((size_t)BN * BKB) + 1024;       // + a spare KiB for padding DMAs
+    size_t lds = round_kb(region0) + wring;
     lds = std::max(lds, (size_t)NW * 2 * 16 * (32 * JG + 4) * sizeof(float));    // two wave-private 16-row epilogue slabs per wave
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const bool seg = a.seg_len > 0;

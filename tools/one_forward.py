@@ -14,10 +14,13 @@ ap.add_argument("--batch", type=int, default=16)
 ap.add_argument("--frames", type=int, default=300)
 ap.add_argument("--precision", default="bf16")
 ap.add_argument("--reps", type=int, default=1)
+ap.add_argument("--tuning", type=int, default=0)
 args = ap.parse_args()
 cfg = q3.flagship_config()
 dec = Decoder(cfg, q3.synthetic_weights(cfg, 0), precision=args.precision, max_frames_per_launch=args.batch * 325)
 codes = q3.random_codes(cfg, args.batch, args.frames, 1).cuda()
+from qwen3_tts_amd import _lib
+_lib.load().q3c_debug_set_tuning(args.tuning)
 for _ in range(1 + args.reps):
     wav = dec.forward(codes)
 torch.cuda.synchronize()
