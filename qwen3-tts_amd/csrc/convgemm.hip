@@ -744,9 +744,11 @@ int pick_shape(const ConvGemmArgs& a, size_t elem) {
     const bool use_96 = (a.act != Q3_ACT_SWIGLU) && (a.N % 128 != 0) && (a.N % 96 == 0) && a.N < 512;
     if (use_96) return SH_256x96;
     if (!wide_k) return SH_128x128_K64;
-    if (!(g_tuning & 2) && a.act != Q3_ACT_SWIGLU && (long long)a.B * a.M >= 8192) {     // enough rows to fill the chip with big tiles
+    // layers of few taps move as many input as weight bytes per step: wider tiles (measured: transposed convs +3..10 %,
+    // k = 7 convs -3 %, which keep 256x128 with 128-byte rows)
+    if (!(g_tuning & 2) && a.act != Q3_ACT_SWIGLU && a.taps <= 3 && (long long)a.B * a.M >= 8192) {
         if (a.N % 256 == 0) return SH_256x256_K64;
-        if (a.N % 192 == 0) return SH_256x192_K64;
+        if (a.N % 192 == 0 && a.taps > 1) return SH_256x192_K64;
     }
     return (g_tuning & 1) ? SH_128x128_K128 : SH_256x128_K128;
 }
