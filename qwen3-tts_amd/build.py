@@ -11,7 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libq3c.so")
-SOURCES = ["convgemm.hip", "kernels.hip", "decoder.cpp"]
+SOURCES = ["convgemm.hip", "convgemm_f32_f32.hip", "convgemm_bf16_bf16.hip", "convgemm_f32_bf16.hip", "convgemm_bf16_f32.hip",
+           "kernels.hip", "decoder.cpp"]
 # no -ffast-math: the RVQ dequantiser and the fp32 parity path rely on IEEE adds / divides
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-x", "hip", "-Wall", "-Wno-unused-function"]
 
@@ -28,7 +29,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "q3c.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "convgemm_impl.h"), os.path.join(HERE, "..", "include", "q3c.h")]
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
@@ -41,7 +42,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=6) as ex:
         list(ex.map(run, jobs))
     objs = [os.path.join(objdir, s + ".o") for s in SOURCES]
     if jobs or force or not _newer(LIB, objs):

@@ -1,0 +1,784 @@
+#pragma once
+// Multi-tap row-shifted GEMM on the gfx950 matrix cores: the one dense-contraction kernel of the decode.
+//
+//   h[b, m, n]   = act( bias[n] + sum_tap sum_k X[b, m + off0 + tap*off_step, k] * W[tap][n][k] ) * scale[n]
+//   FUSE2 only:    h <- bias2[n] + sum_j h[b, m, j] * W2[n][j]                (a second, 1x1 contraction in the same launch)
+//   y            = R[b, m, n] + h
+//   Y <- y (or post(y) when Y2 is null);   Y2 <- post(y)                      (post = SnakeBeta of the consumer)
+//
+// With channels-last activations every layer of the decoder is this form:
+//   causal Conv1d(k, dilation d)      taps = k, off0 = -(k-1)d, off_step = d
+//   ConvTranspose1d(k = 2s, stride s) taps = 2, off0 = 0, off_step = 1, N = s*Cout  (row q of [L-1, s*Cout] IS rows q*s .. q*s+s-1 of [.., Cout])
+//   ConvTranspose1d(k = s,  stride s) taps = 1, N = s*Cout
+//   Linear                            taps = 1
+//   residual unit                     FUSE2: conv k7 -> snake -> conv k1 -> + x in ONE launch (its input arrives already
+//                                     passed through the unit's first snake by the producing kernel's epilogue)
+//
+// A block owns a BM x BN output tile.  Per K-chunk the (BM + halo) input rows are staged ONCE in LDS and every tap
+// reads them at a row offset, so the im2col matrix never exists.  Weight tiles are staged per (K-chunk, tap) step,
+// two steps ahead in three buffers; the next chunk's input tile arrives in slices spread over the current chunk's
+// steps.  Both go global -> LDS directly (LDS-DMA: `global_load_lds` / `buffer_load ... lds`, 16 bytes per lane), rows
+// outside the sequence zero-filled by the buffer descriptor's range check; each wave waits with a counted vmcnt.
+// LDS rows are BKB bytes; 16-byte chunk c of row r sits at slot c ^ f(r), so the 16-lane groups of ds_read_b128 touch
+// 16 distinct slots; with LDS-DMA the destination is lane-linear and the XOR is applied to the SOURCE address.
+//
+// Element types: bf16 operands -> v_mfma_f32_32x32x16_bf16; fp32 operands -> v_mfma_f32_32x32x2_f32 (bit-exact fp32
+// FMA chains, used by the parity path).  Accumulation is fp32 in both.
+#include "common.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <type_traits>
+
+extern int q3_convgemm_tuning;
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void global_cvoid;
+
+template <int CPR> __device__ __forceinline__ int swz(int row, int c) {
+    if constexpr (CPR == 8) return c ^ ((row >> 1) & 7);
+    else return c ^ ((row >> 2) & 3);
+}
+
+template <typename TA> struct Mma;
+template <> struct Mma<bf16> {
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    // lane half h holds k = 4h .. 4h+3 of an 8-deep group for BOTH operands; MFMA j contracts k in {j, 4 + j}
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, b.x), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.y), __builtin_bit_cast(float, b.y), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.z), __builtin_bit_cast(float, b.z), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.w), __builtin_bit_cast(float, b.w), c, 0, 0, 0);
+    }
+};
+
+__host__ __device__ constexpr size_t round_kb(size_t v) { return (v + 1023) / 1024 * 1024; }
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n: all but the n youngest vector-memory operations are done.
+// n above 7 waits for vmcnt(7) (always safe: it only waits longer).
+__device__ __forceinline__ void wait_vmcnt(int n) {
+    if (n >= 4) {
+        if (n >= 6) { if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); }
+        else { if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
+    } else {
+        if (n >= 2) { if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
+        else { if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    }
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt_c() {
+    static_assert(N >= 0 && N <= 15, "vmcnt immediate");
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+}
+// One LDS-DMA instruction: 16 bytes per lane from global memory to LDS at lds_addr + lane * 16 (lds_addr wave-uniform).
+// Issued through inline asm on purpose: the compiler then neither counts it nor guards later ds_reads with vmcnt(0), so
+// tiles can stay in flight across steps; completion is tracked by wait_vmcnt below.  M0 (the LDS base of an LDS-DMA) is
+// written in the same statement; nothing else in these kernels uses M0.
+//   dma16    : every lane supplies a full 64-bit address
+//   dma16_so : wave-uniform 64-bit base (SGPR pair) + unsigned 32-bit per-lane byte offset
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_addr) {
+    lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);      // wave-uniform by construction; pins it to an SGPR
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void dma16_so(const void* sbase, unsigned voff, unsigned lds_addr) {
+    lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ unsigned lds_address(const void* generic_ptr_into_lds) {
+    return (unsigned)(unsigned long long)(lds_void*)generic_ptr_into_lds;
+}
+__device__ __forceinline__ void block_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <typename TA, typename TO, int WAVES_M, int WAVES_N, int WM, int WN, int BKB, bool FUSE2, bool SEG>
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const ConvGemmArgs p) {
+    constexpr int NW = WAVES_M * WAVES_N;            // waves per block
+    constexpr int NTHR = 64 * NW;
+    constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
+    constexpr int CPR = BKB / 16;                    // 16-byte chunks per LDS row
+    constexpr int EPC = ElemTraits<TA>::EPC;         // elements per chunk
+    constexpr int BK = CPR * EPC;                    // K elements per chunk row
+    constexpr int KG = BKB / 32;                     // fragment groups per step
+    constexpr int WPIECES = BN * CPR;
+    constexpr int WITER = (WPIECES + NTHR - 1) / NTHR;
+    constexpr size_t WBUF = round_kb((size_t)BN * BKB);
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per block");
+    static_assert(NTHR % CPR == 0, "column chunk of a thread is fixed");
+    static_assert(!FUSE2 || WAVES_N == 1, "the fused second contraction needs whole rows per wave");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    // 1-D tile index with the N tiles fastest.  Workgroups are dealt round-robin over the 8 XCDs (each with its own
+    // L2), so workgroup ids congruent mod 8 share an L2: give each such group a CONTIGUOUS run of tiles, so the blocks
+    // that read the same input rows (the N tiles of one M tile) and walk the same weights run side by side on one L2.
+    const int n_tiles = (p.N + BN - 1) / BN;
+    int b = blockIdx.y;
+    int tile = blockIdx.x;
+    int n0, m0;
+    if (!(p.debug & 16)) {
+        const int wg = blockIdx.y * gridDim.x + blockIdx.x;        // dispatch order: x fastest
+        const int nwg = gridDim.x * gridDim.y, q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
+        const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+        // Which operand is worth keeping in the XCD's L2 decides the order inside its run of tiles.  Multi-tap layers
+        // re-stream taps x BN x K of weights per block: N tile slowest over the WHOLE grid, so the run walks down the
+        // rows of one or two N tiles.  Single-tap layers have small weights and an input tile as large as the output:
+        // N tile fastest, so the blocks sharing an input tile run side by side and it comes from HBM once.
+        if ((p.taps > 1) != ((p.debug & 32) != 0)) {
+            const int m_tiles = gridDim.x / n_tiles, per_n = m_tiles * gridDim.y;
+            const int nt = id / per_n, rest = id - nt * per_n;
+            b = rest / m_tiles;
+            n0 = nt * BN;
+            m0 = (rest - b * m_tiles) * BM;
+        } else {
+            b = id / (int)gridDim.x;
+            tile = id - b * (int)gridDim.x;
+            n0 = (tile % n_tiles) * BN;
+            m0 = (tile / n_tiles) * BM;
+        }
+    } else {
+        n0 = (tile % n_tiles) * BN;
+        m0 = (tile / n_tiles) * BM;
+    }
+
+    const int halo = (p.taps - 1) * p.off_step;
+    const int HR = BM + halo;                        // staged input rows
+    const int xpieces = HR * CPR;
+    const int xi_total = (xpieces + NTHR - 1) / NTHR;
+    const int xps = (xi_total + p.taps - 1) / p.taps;   // pieces per thread per step (<= MAX_XPS, host-checked)
+    const size_t XBUF = (size_t)xi_total * NW * 1024;          // whole slices: every wave of every slice has its KiB
+    const size_t hs_bytes = (size_t)BM * (p.N * sizeof(TA) + 16);
+    // single-tap layers (k = 1 convs, linears) use a fresh input tile every step: three buffers, fetched two steps
+    // ahead like the weights; multi-tap layers keep a tile for `taps` steps: two buffers, the next one filled in slices
+    // layers of two or three taps also get three (when they fit): their chunks are too short to hide an HBM fetch
+    const int nxb = p.nxb;
+    const size_t region0 = (FUSE2 && hs_bytes > nxb * XBUF) ? hs_bytes : nxb * XBUF;
+
+    unsigned char* Xs0 = smem;                       // the input buffers
+    unsigned char* Ws0 = smem + round_kb(region0);   // three weight buffers
+
+    const TA* __restrict__ Xb = (const TA*)p.X + (long long)b * p.x_batch_stride;
+    const TA* __restrict__ Wg = (const TA*)p.W;
+    const int nkc = (p.K + BK - 1) / BK;
+    const int nsteps = nkc * p.taps;
+    const int my_c = tid % CPR;                      // column chunk of every piece this thread stages
+    const bool dma = (p.K % BK) == 0;                // whole chunks only: LDS-DMA cannot zero-fill a K tail
+
+    const int g0 = m0 + p.off0;                      // sequence row of staged row 0
+
+    // ---- input tile, register path (K tail only) ----
+    auto x_load = [&](int id, int kc) -> uint4 {
+        int row = id / CPR;
+        int grow = g0 + row;
+        int kel = kc * BK + my_c * EPC;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (id < xpieces && grow >= 0 && grow < p.L_in && kel < p.K)
+            v = *(const uint4*)(Xb + (long long)grow * p.ldx + kel);
+        return v;
+    };
+    auto x_store = [&](unsigned char* xs, int id, uint4 v) {
+        if (id < xpieces) {
+            int row = id / CPR;
+            *(uint4*)(xs + (size_t)row * BKB + swz<CPR>(row, my_c) * 16) = v;
+        }
+    };
+    // ---- weight tile ----
+    auto w_load = [&](const TA* W, int ldw, int id, int kc, int tap) -> uint4 {
+        int row = id / CPR, c = id % CPR;
+        int n = n0 + row;
+        int kel = kc * BK + c * EPC;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (id < WPIECES && n < p.N && kel < ldw)
+            v = *(const uint4*)(W + ((long long)tap * p.N + n) * ldw + kel);
+        return v;
+    };
+    auto w_store = [&](unsigned char* ws, int id, uint4 v) {
+        if (id < WPIECES) {
+            int row = id / CPR, c = id % CPR;
+            *(uint4*)(ws + (size_t)row * BKB + swz<CPR>(row, c) * 16) = v;
+        }
+    };
+    // ---- LDS-DMA staging.  LDS destinations are lane-linear (1 KiB per wave instruction), so the chunk XOR is applied
+    //      to the SOURCE address.  Every call issues a fixed number of DMA instructions per wave (waves with nothing to
+    //      fetch aim a padding DMA at a spare KiB) so that the vmcnt bookkeeping needs no per-wave counts.
+    const unsigned lds0 = lds_address(smem);
+    const unsigned xs_lds = lds0, ws_lds = lds0 + (unsigned)round_kb(region0);
+    const unsigned spare_lds = ws_lds + 3 * (unsigned)WBUF;
+    const unsigned char* zero_page = (const unsigned char*)p.zeros;
+    constexpr int XROWS_PER_IT = NTHR / CPR;                     // rows one iteration of all waves covers (a multiple of 16)
+    const int xrow0 = tid / CPR;
+    // a tile whose staged rows (padding lanes included) all lie inside the sequence needs no per-lane checks
+    const bool interior = g0 >= 0 && (g0 + xi_total * XROWS_PER_IT) <= p.L_in;
+    const TA* xtile = Xb + (long long)g0 * p.ldx;                                      // wave-uniform
+    const unsigned xvoff0 = (unsigned)((xrow0 * p.ldx + swz<CPR>(xrow0, my_c) * EPC) * (int)sizeof(TA));
+    // input rows [it*XROWS_PER_IT ...) of chunk kc -> buffer at xs; rows outside the sequence come from the zero page
+    auto x_dma_issue = [&](unsigned xs, int it, int kc) {
+        const int slot = it * NW + wave;
+        if (it >= xi_total) { dma16_so(zero_page, 0u, spare_lds); return; }     // a step with no slice left: padding DMA
+        const TA* sbase = xtile + ((long long)it * XROWS_PER_IT * p.ldx + kc * BK);
+        if (interior) {
+            dma16_so(sbase, xvoff0, xs + (unsigned)slot * 1024u);
+        } else {
+            const int grow = g0 + xrow0 + it * XROWS_PER_IT;
+            const unsigned long long real = (unsigned long long)sbase + xvoff0;
+            const unsigned long long src = (grow >= 0 && grow < p.L_in) ? real : (unsigned long long)zero_page;
+            dma16((const void*)src, xs + (unsigned)slot * 1024u);
+        }
+    };
+    unsigned wvoff[WITER], w2voff[WITER];
+#pragma unroll
+    for (int q = 0; q < WITER; ++q) {
+        const int id = (q * NW + wave) * 64 + lane;
+        const int row = id / CPR, cs = id % CPR;
+        int n = n0 + row;
+        n = n < p.N ? n : p.N - 1;                               // columns past N are never stored: any finite row will do
+        wvoff[q] = (unsigned)((n * p.K + swz<CPR>(row, cs) * EPC) * (int)sizeof(TA));
+        w2voff[q] = (unsigned)((n * p.N + swz<CPR>(row, cs) * EPC) * (int)sizeof(TA));
+    }
+    auto w_dma_one = [&](unsigned ws, const TA* sbase, const unsigned* voff, int q) {
+        if (WITER * NW * 64 == WPIECES || (q * NW + wave) * 64 < WPIECES) dma16_so(sbase, voff[q], ws + (unsigned)(q * NW + wave) * 1024u);
+        else dma16_so(zero_page, 0u, spare_lds);
+    };
+    auto w_dma_issue = [&](unsigned ws, const TA* sbase, const unsigned* voff) {
+#pragma unroll
+        for (int q = 0; q < WITER; ++q) w_dma_one(ws, sbase, voff, q);
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // MFMAs of one step: every wave multiplies its rows of the staged input (shifted by the tap) with the weight tile.
+    // The fragments of group kg + 1 are read from LDS before the MFMAs of group kg issue, so a wave's LDS latency hides
+    // under its own matrix work.  `between(kg)` runs ahead of group kg: the pipeline issues its LDS-DMAs there, spread
+    // over the groups, so the address unit works through them while the matrix cores run.
+    auto compute = [&](const unsigned char* xs, const unsigned char* ws, int row_shift, auto&& between) {
+        const int arow0 = wm * 32 * WM + (lane & 31) + row_shift;
+        const int brow0 = wn * 32 * WN + (lane & 31);
+        uint4 af[2][WM], bfr[2][WN];
+        auto load = [&](int buf, int kg) {
+            const int c = kg * 2 + (lane >> 5);
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+                int row = arow0 + i * 32;
+                af[buf][i] = *(const uint4*)(xs + (size_t)row * BKB + swz<CPR>(row, c) * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                int row = brow0 + j * 32;
+                bfr[buf][j] = *(const uint4*)(ws + (size_t)row * BKB + swz<CPR>(row, c) * 16);
+            }
+        };
+        load(0, 0);
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) {
+            between(kg);
+            if (kg + 1 < KG) load((kg + 1) & 1, kg + 1);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) Mma<TA>::run(af[kg & 1][i], bfr[kg & 1][j], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+        }
+    };
+
+    if (dma) {
+        // ---- LDS-DMA pipeline: weight tiles two steps ahead in three buffers, the next chunk's input tile in slices
+        //      spread over this chunk's steps; each step waits with vmcnt(n) for all but the DMAs that may stay in
+        //      flight, then one raw barrier.  The slice count per step is a compile-time constant of the loop (one
+        //      instantiation per value) so that the steady-state waits are immediates and the slice loop unrolls.
+        const long long tap_stride = (long long)p.N * p.K;       // elements between taps of W
+        const long long slice_stride = (long long)XROWS_PER_IT * p.ldx;   // elements between input slices
+        // single-tap steady state needs at least one step with a tile two steps on
+        const bool lean1 = p.taps == 1 && nxb == 3 && interior && nsteps >= 3;
+        const bool lean2 = p.taps > 1 && nxb == 3 && interior && nkc >= 3;       // multi-tap, input tiles two chunks ahead
+        const int x_ahead = lean2 ? 2 : 1;
+        for (int it = 0; it < xi_total; ++it) x_dma_issue(xs_lds, it, 0);
+        w_dma_issue(ws_lds, Wg, wvoff);
+        if (nsteps > 1) {
+            w_dma_issue(ws_lds + (unsigned)WBUF, Wg + (p.taps > 1 ? tap_stride : (long long)BK), wvoff);
+            if (lean1 || lean2) for (int it = 0; it < xi_total; ++it) x_dma_issue(xs_lds + (unsigned)XBUF, it, 1);
+            wait_vmcnt(WITER + ((lean1 || lean2) ? xi_total : 0));
+        } else {
+            wait_vmcnt(0);
+        }
+        block_barrier();
+        // pipeline state, shared by the loops below
+        int step = 0, kc = 0, tap = 0, wb = 0, xb = 0;           // wb / xb: weight / input buffer of the current step
+        int x_issued = (lean1 || lean2) ? 1 : 0;                 // highest chunk whose input tile has been requested
+        int ltap = p.taps > 2 ? 2 : 0, lkc = p.taps > 2 ? 0 : (p.taps == 2 ? 1 : 2);   // (tap, chunk) of step + 2
+        const TA* wsrc = Wg + (ltap * tap_stride + (long long)lkc * BK);               // weight tile of step + 2
+        const TA* xsrc = xtile + (long long)x_ahead * BK;        // slice `xit` of the chunk being fetched (interior tiles)
+        int xit = 0;
+        auto advance = [&](bool boundary, int xps_c) {
+            if (boundary) { tap = 0; ++kc; xit = 0; xsrc = xtile + (long long)(kc + x_ahead) * BK; xb = xb + 1 == nxb ? 0 : xb + 1; }
+            else { ++tap; xit += xps_c; xsrc += xps_c * slice_stride; }
+            wsrc += tap_stride;
+            if (++ltap == p.taps) { ltap = 0; ++lkc; wsrc += (long long)BK - p.taps * tap_stride; }
+            wb = wb == 2 ? 0 : wb + 1;
+        };
+        // Steady state of an interior tile (every staged row inside the sequence, a next chunk and a weight tile two
+        // steps on still to fetch): no per-lane or per-step conditions, immediates for the waits.  Issue slots are the
+        // scarce resource next to the matrix pipe - every instruction a wave issues here adds to the step's time.
+        auto lean = [&](auto xps_tag, int lean_steps) {
+            constexpr int XPS = decltype(xps_tag)::value;
+            const unsigned xdst_w = xs_lds + (unsigned)wave * 1024u, wdst_w = ws_lds + (unsigned)wave * 1024u;
+            // steps between the request of a chunk's last real slice and the chunk's first use (two chunks ahead: plenty)
+            const int slack = lean2 ? 2 : p.taps - (xi_total + XPS - 1) / XPS;
+            for (; step < lean_steps; ++step) {
+                const unsigned xsn = xdst_w + (unsigned)((lean2 ? (xb == 0 ? 2 : xb - 1) : (xb ^ 1)) * XBUF);
+                const unsigned wsn = wdst_w + (unsigned)((wb == 0 ? 2 : wb - 1) * WBUF);
+                // this step's DMAs, oldest first: the weight tile of step + 2 (groups 0..), then the next chunk's input slices
+                // (last group).  Loads retire in order, so a weight tile can only be waited for together with everything
+                // issued before it: the slices, which come from HBM and take longest, go last and get a whole extra step.
+                compute(Xs0 + (size_t)xb * XBUF, Ws0 + (size_t)wb * WBUF, tap * p.off_step, [&](int kg) {
+#pragma unroll
+                    for (int q = 0; q < WITER; ++q)
+                        if ((q < KG ? q : KG - 1) == kg) {
+                            if (WITER * NW * 64 == WPIECES || (q * NW + wave) * 64 < WPIECES) dma16_so(wsrc, wvoff[q], wsn + (unsigned)(q * NW) * 1024u);
+                            else dma16_so(zero_page, 0u, spare_lds);
+                        }
+                    if (kg == KG - 1) {
+#pragma unroll
+                        for (int i = 0; i < XPS; ++i) {
+                            if (xit + i < xi_total) dma16_so(xsrc + i * slice_stride, xvoff0, xsn + (unsigned)((xit + i) * NW) * 1024u);
+                            else dma16_so(zero_page, 0u, spare_lds);
+                        }
+                    }
+                });
+                // The next step reads weight tile step + 1, issued a step ago and followed since by that step's slices,
+                // this step's weight tile and this step's slices: those may stay in flight.  A step that closes a chunk
+                // also needs the chunk's last real slice; when the slices ran out two or more steps ago that is implied.
+                const bool boundary = (tap + 1) == p.taps;
+                if (step == 0) wait_vmcnt(WITER + XPS);
+                else if (boundary && slack < 2) wait_vmcnt(slack == 1 ? WITER + XPS : 0);
+                else wait_vmcnt_c<WITER + 2 * XPS>();
+                block_barrier();
+                advance(boundary, XPS);
+            }
+            x_issued = kc + x_ahead - 1;    // the general loop requests chunk kc + 1 itself when it is not among these
+        };
+        // Single-tap steady state: input tile AND weight tile of step + 2 requested every step, three buffers each.
+        auto lean_single = [&](auto xps_tag, int lean_steps) {
+            constexpr int XPS = decltype(xps_tag)::value;            // == xi_total: the whole tile every step
+            const unsigned xdst_w = xs_lds + (unsigned)wave * 1024u, wdst_w = ws_lds + (unsigned)wave * 1024u;
+            const TA* xsrc2 = xtile + 2 * BK;                        // input tile of step + 2
+            for (; step < lean_steps; ++step) {
+                const unsigned xsn = xdst_w + (unsigned)((xb == 0 ? 2 : xb - 1) * XBUF);
+                const unsigned wsn = wdst_w + (unsigned)((wb == 0 ? 2 : wb - 1) * WBUF);
+                compute(Xs0 + (size_t)xb * XBUF, Ws0 + (size_t)wb * WBUF, 0, [&](int kg) {
+#pragma unroll
+                    for (int q = 0; q < WITER; ++q)
+                        if ((q < KG ? q : KG - 1) == kg) {
+                            if (WITER * NW * 64 == WPIECES || (q * NW + wave) * 64 < WPIECES) dma16_so(wsrc, wvoff[q], wsn + (unsigned)(q * NW) * 1024u);
+                            else dma16_so(zero_page, 0u, spare_lds);
+                        }
+                    // the tile's slices spread over the later groups
+#pragma unroll
+                    for (int i = 0; i < XPS; ++i)
+                        if ((KG - 1 - (XPS - 1 - i) * (KG - 1) / (XPS > 1 ? XPS - 1 : 1)) == kg)
+                            dma16_so(xsrc2 + i * slice_stride, xvoff0, xsn + (unsigned)(i * NW) * 1024u);
+                });
+                wait_vmcnt_c<WITER + XPS>();       // all but this step's requests: tiles of step + 1 are in
+                block_barrier();
+                xsrc2 += BK;
+                advance(true, XPS);
+            }
+            x_issued = nkc - 1;
+        };
+        auto pipeline = [&](auto xps_tag) {
+            constexpr int XPS = decltype(xps_tag)::value;
+            for (; step < nsteps; ++step) {
+                const int wb2 = wb == 0 ? 2 : wb - 1;
+                const bool more_x = (kc + 1) < nkc && (kc + 1) > x_issued, more_w = (step + 2) < nsteps;
+                const unsigned xsn = xs_lds + (unsigned)((xb + 1 == nxb ? 0 : xb + 1) * XBUF);
+                const unsigned wsn = ws_lds + (unsigned)(wb2 * WBUF);
+                // same issue order as the steady-state loop; the waits let only THIS step's DMAs stay in flight, which is
+                // right whatever the steps before left outstanding
+                compute(Xs0 + (size_t)xb * XBUF, Ws0 + (size_t)wb * WBUF, tap * p.off_step, [&](int kg) {
+                    if (more_w) {
+#pragma unroll
+                        for (int q = 0; q < WITER; ++q)
+                            if ((q < KG ? q : KG - 1) == kg) w_dma_one(wsn, wsrc, wvoff, q);
+                    }
+                    if (kg == KG - 1 && more_x) {
+#pragma unroll 1
+                        for (int i = 0; i < XPS; ++i) x_dma_issue(xsn, xit + i, kc + 1);
+                    }
+                });
+                const bool boundary = (tap + 1) == p.taps;
+                if (boundary) wait_vmcnt(more_x ? 0 : (more_w ? WITER : 0));
+                else wait_vmcnt((more_w ? WITER : 0) + (more_x ? XPS : 0));
+                block_barrier();
+                advance(boundary, XPS);
+            }
+        };
+        const int lean_steps = lean1 ? nsteps - 2 : lean2 ? (nkc - 2) * p.taps
+                             : (interior && nkc >= 2 && p.taps >= 2 && nxb == 2) ? (nkc - 1) * p.taps : 0;
+        auto run = [&](auto tag) {
+            if (lean1) lean_single(tag, lean_steps); else lean(tag, lean_steps);
+            pipeline(tag);
+        };
+        switch (xps) {
+            case 1: run(std::integral_constant<int, 1>{}); break;
+            case 2: run(std::integral_constant<int, 2>{}); break;
+            case 3: run(std::integral_constant<int, 3>{}); break;
+            default: run(std::integral_constant<int, 4>{}); break;
+        }
+    } else {
+        // ---- K tail (narrow test shapes): synchronous register staging, zero-filled past K ----
+        int kc = 0, tap = 0;
+        for (int step = 0; step < nsteps; ++step) {
+            if (tap == 0)
+                for (int it = 0; it < xi_total; ++it) x_store(Xs0, tid + it * NTHR, x_load(tid + it * NTHR, kc));
+#pragma unroll
+            for (int it = 0; it < WITER; ++it) w_store(Ws0, tid + it * NTHR, w_load(Wg, p.K, tid + it * NTHR, kc, tap));
+            __syncthreads();
+            compute(Xs0, Ws0, tap * p.off_step, [](int) {});
+            __syncthreads();
+            if (++tap == p.taps) { tap = 0; ++kc; }
+        }
+    }
+
+    const int half = lane >> 5, l31 = lane & 31;
+
+    // ---- fused second contraction (k = 1): h = snake(acc + bias) -> LDS -> acc = h . W2^T -------------------------
+    if (FUSE2) {
+        const int HLD = p.N * (int)sizeof(TA) + 16;                 // padded row stride of the h tile
+        unsigned char* Hs = smem;                                   // overlays the (now idle) input buffers
+        const TA* __restrict__ W2 = (const TA*)p.W2;
+        const bool w2_dma = (p.N % BK) == 0;      // the h tile is consumed in whole chunks too
+        // first W2 tile in flight while h is produced
+        if (w2_dma) w_dma_issue(ws_lds, W2, w2voff);
+        else {
+#pragma unroll
+            for (int it = 0; it < WITER; ++it) w_store(Ws0, tid + it * NTHR, w_load(W2, p.N, tid + it * NTHR, 0, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const int n = j * 32 + l31;
+                const bool nv = n < p.N;
+                const float bias = (p.bias && nv) ? p.bias[n] : 0.f;
+                float ea = 0.f, eib = 0.f;
+                if (p.act == Q3_ACT_SNAKE && nv) { ea = p.epi_a[n]; eib = p.epi_invb[n]; }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    float v = acc[i][j][r] + bias;
+                    if (p.act == Q3_ACT_SNAKE) v = q3_snake<TA>(v, ea, eib);
+                    if (nv) *(TA*)(Hs + (size_t)row * HLD + n * sizeof(TA)) = q3_from_f32<TA>(v);
+                    acc[i][j][r] = 0.f;
+                }
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int nkc2 = (p.N + BK - 1) / BK;
+        for (int s2 = 0; s2 < nkc2; ++s2) {
+            const bool has_next = (s2 + 1) < nkc2;
+            unsigned char* wsn = Ws0 + (size_t)((s2 + 1) & 1) * WBUF;
+            uint4 wreg[WITER];
+            if (has_next) {
+                if (w2_dma) w_dma_issue(ws_lds + (unsigned)(((s2 + 1) & 1) * WBUF), W2 + (long long)(s2 + 1) * BK, w2voff);
+                else {
+#pragma unroll
+                    for (int it = 0; it < WITER; ++it) wreg[it] = w_load(W2, p.N, tid + it * NTHR, s2 + 1, 0);
+                }
+            }
+            const unsigned char* ws = Ws0 + (size_t)(s2 & 1) * WBUF;
+            const int arow0 = wm * 32 * WM + l31;
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg) {
+                const int c = kg * 2 + half;
+                const int kbyte = s2 * BKB + c * 16;
+                uint4 af[WM], bfr[WN];
+#pragma unroll
+                for (int i = 0; i < WM; ++i) {
+                    // columns past N (a K tail of the last chunk) multiply zero-filled weight columns; read them as zero too
+                    af[i] = (kbyte < p.N * (int)sizeof(TA)) ? *(const uint4*)(Hs + (size_t)(arow0 + i * 32) * HLD + kbyte)
+                                                            : make_uint4(0, 0, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    int row = j * 32 + l31;
+                    bfr[j] = *(const uint4*)(ws + (size_t)row * BKB + swz<CPR>(row, c) * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) Mma<TA>::run(af[i], bfr[j], acc[i][j]);
+            }
+            if (has_next && !w2_dma) {
+#pragma unroll
+                for (int it = 0; it < WITER; ++it) w_store(wsn, tid + it * NTHR, wreg[it]);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue -----------------------------------------------------------------------------------
+    // The accumulator layout gives each lane ONE column of 16 rows, while memory wants 16 contiguous bytes per lane.
+    // Each wave therefore passes its tile through private fp32 LDS slabs, 16 rows x <= 96 columns at a time:
+    //   phase 0  residual rows -> slab A            (row-wise, 16-byte loads)
+    //   phase 1  accumulator + bias, activation, scale, + slab A  -> slab A (raw), snake of the consumer -> slab B
+    //            (column-wise: the per-channel parameters are two registers per lane)
+    //   phase 2  slab A -> Y, slab B -> Y2           (row-wise, 16-byte stores)
+    TO* __restrict__ Yb = (TO*)p.Y + (long long)b * p.y_batch_stride;
+    TO* __restrict__ Y2b = p.Y2 ? (TO*)p.Y2 + (long long)b * p.y2_batch_stride : nullptr;
+    const TO* __restrict__ Rb = p.R ? (const TO*)p.R + (long long)b * p.r_batch_stride : nullptr;
+    constexpr int EPO = 16 / (int)sizeof(TO);            // output elements per 16-byte piece
+    constexpr int JG = WN <= 4 ? WN : 3;                  // column tiles per slab pass
+    constexpr int SCOLS = 32 * JG;
+    constexpr int SLD = SCOLS + 4;                        // slab row stride in floats (keeps rows 16-byte aligned)
+    constexpr int SROWS = 16;
+    static_assert(WN % JG == 0, "slab passes must tile the wave's columns");
+    float* slabA = (float*)smem + wave * (2 * SROWS * SLD);
+    float* slabB = slabA + SROWS * SLD;
+    const bool swiglu = p.act == Q3_ACT_SWIGLU;
+    const int n_out = swiglu ? p.N / 2 : p.N;
+    const bool has_post = p.post_a != nullptr;
+    const bool vec_ok = (p.ldy % EPO == 0) && (!Rb || p.ldr % EPO == 0) && (n_out % EPO == 0);
+    const int first_act = FUSE2 ? Q3_ACT_NONE : p.act;    // FUSE2 consumed the activation before its second contraction
+    const float* obias = FUSE2 ? p.bias2 : p.bias;
+    // Segmented rows (streams stacked in one row space, each segment = carried rows + new rows): GEMM row m belongs
+    // to segment m / seg_len and is output row m % seg_len - seg_hist of it; carried rows produce no output.
+    // SEG instantiations serve the streaming decode only; the bulk path compiles to plain row addressing.
+    auto locate = [&](int m, int& bb, int& r) -> bool {
+        bb = 0; r = m;
+        if (m >= p.M) return false;
+        if constexpr (SEG) { bb = m / p.seg_len; r = m - bb * p.seg_len - p.seg_hist; }
+        return r >= 0;
+    };
+
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+        for (int jg = 0; jg < WN; jg += JG) {
+            const int pcols = swiglu ? SCOLS / 2 : SCOLS;              // output columns of this pass
+            const int ncol0 = swiglu ? ((n0 >> 1) + wn * (16 * WN) + (jg >> 1) * 32) : (n0 + wn * 32 * WN + jg * 32);
+            const int cprw = pcols / EPO;                               // 16-byte pieces per slab row
+#pragma unroll
+            for (int rh = 0; rh < 2; ++rh) {                            // rows 0-15, then 16-31 of the 32-row tile
+                const int mrow0 = m0 + wm * 32 * WM + i * 32 + rh * 16;
+                // phase 0: residual -> slab A
+                if (Rb) {
+                    for (int id = lane; id < SROWS * cprw; id += 64) {
+                        const int row = id / cprw, ch = id - row * cprw;
+                        const int m = mrow0 + row, n = ncol0 + ch * EPO;
+                        float v[EPO];
+#pragma unroll
+                        for (int e = 0; e < EPO; ++e) v[e] = 0.f;
+                        int bb, r;
+                        if (locate(m, bb, r) && n < n_out) {
+                            const TO* Rr = Rb + (SEG ? (long long)bb * p.r_batch_stride : 0LL) + (long long)r * p.ldr;
+                            if (vec_ok) {
+                                const uint4 raw = *(const uint4*)(Rr + n);
+                                const TO* rr = (const TO*)&raw;
+#pragma unroll
+                                for (int e = 0; e < EPO; ++e) v[e] = q3_to_f32(rr[e]);
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < EPO; ++e)
+                                    if (n + e < n_out) v[e] = q3_to_f32(Rr[n + e]);
+                            }
+                        }
+                        float* sp = slabA + row * SLD + ch * EPO;
+#pragma unroll
+                        for (int e = 0; e < EPO; e += 4) *(float4*)(sp + e) = make_float4(v[e], v[e + 1], v[e + 2], v[e + 3]);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                // phase 1: column-wise math
+                if (swiglu) {
+                    if constexpr (JG % 2 == 0) {
+#pragma unroll
+                        for (int j = 0; j < JG; j += 2) {
+                            const int cl = (j >> 1) * 32 + l31;
+                            const int n = ncol0 + cl;
+                            const float sc = (p.scale && n < n_out) ? p.scale[n] : 1.f;
+#pragma unroll
+                            for (int r8 = 0; r8 < 8; ++r8) {
+                                const int r = rh * 8 + r8;
+                                const int row = (r8 & 3) + 8 * (r8 >> 2) + 4 * half;
+                                float v = q3_silu(acc[i][jg + j][r]) * acc[i][jg + j + 1][r] * sc;
+                                if (Rb) v += slabA[row * SLD + cl];
+                                slabA[row * SLD + cl] = v;
+                            }
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < JG; ++j) {
+                        const int cl = j * 32 + l31;
+                        const int n = ncol0 + cl;
+                        const bool nv = n < n_out;
+                        const float bias = (obias && nv) ? obias[n] : 0.f;
+                        const float sc = (p.scale && nv && !FUSE2) ? p.scale[n] : 1.f;
+                        float ea = 0.f, eib = 0.f, qa = 0.f, qib = 0.f;
+                        if (first_act == Q3_ACT_SNAKE && nv) { ea = p.epi_a[n]; eib = p.epi_invb[n]; }
+                        if (has_post && nv) { qa = p.post_a[n]; qib = p.post_invb[n]; }
+#pragma unroll
+                        for (int r8 = 0; r8 < 8; ++r8) {
+                            const int r = rh * 8 + r8;
+                            const int row = (r8 & 3) + 8 * (r8 >> 2) + 4 * half;
+                            float v = acc[i][jg + j][r] + bias;
+                            if (first_act == Q3_ACT_GELU) v = q3_gelu(v);
+                            else if (first_act == Q3_ACT_SNAKE) v = q3_snake<TO>(v, ea, eib);
+                            else if (first_act == Q3_ACT_CLAMP) v = fminf(1.0f, fmaxf(-1.0f, v));
+                            v *= sc;
+                            if (Rb) v += slabA[row * SLD + cl];
+                            if (Y2b) {
+                                slabA[row * SLD + cl] = v;
+                                slabB[row * SLD + cl] = q3_snake<TO>(v, qa, qib);
+                            } else {
+                                slabA[row * SLD + cl] = has_post ? q3_snake<TO>(v, qa, qib) : v;
+                            }
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                // phase 2: slabs -> memory, 16 bytes per lane
+                for (int id = lane; id < SROWS * cprw; id += 64) {
+                    const int row = id / cprw, ch = id - row * cprw;
+                    const int m = mrow0 + row, n = ncol0 + ch * EPO;
+                    int bb, r;
+                    if (!locate(m, bb, r) || n >= n_out) continue;
+                    const long long yo = (long long)r * p.ldy + n;
+                    const bool blank = SEG && p.row_start && r < p.row_start[bb];   // rows before a stream's first sample
+#pragma unroll
+                    for (int which = 0; which < 2; ++which) {
+                        if (which == 1 && !Y2b) break;
+                        const float* sp = (which ? slabB : slabA) + row * SLD + ch * EPO;
+                        TO* dst = (which ? Y2b : Yb) + yo;
+                        if constexpr (SEG) dst += (long long)bb * (which ? p.y2_batch_stride : p.y_batch_stride);
+                        float v[EPO];
+#pragma unroll
+                        for (int e = 0; e < EPO; e += 4) {
+                            const float4 t4 = blank ? make_float4(0.f, 0.f, 0.f, 0.f) : *(const float4*)(sp + e);
+                            v[e] = t4.x; v[e + 1] = t4.y; v[e + 2] = t4.z; v[e + 3] = t4.w;
+                        }
+                        if (vec_ok) {
+                            uint4 outv;
+                            TO* oo = (TO*)&outv;
+#pragma unroll
+                            for (int e = 0; e < EPO; ++e) oo[e] = q3_from_f32<TO>(v[e]);
+                            *(uint4*)dst = outv;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < EPO; ++e)
+                                if (n + e < n_out) dst[e] = q3_from_f32<TO>(v[e]);
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------
+// A/B switches for measurements, defined in convgemm.hip: bit 0 = 4-wave 128x128 tiles, bit 1 = no wide tiles;
+// bits 8.. are handed to the kernel as ConvGemmArgs::debug
+
+
+template <typename TA, typename TO, int WAVES_M, int WAVES_N, int WM, int WN, int BKB, bool FUSE2>
+hipError_t launch_cfg(const ConvGemmArgs& a_in, hipStream_t s) {
+    constexpr int NW = WAVES_M * WAVES_N, NTHR = 64 * NW;
+    constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
+    constexpr int CPR = BKB / 16;
+    constexpr int JG = WN <= 4 ? WN : 3;
+    ConvGemmArgs a = a_in;
+    const int halo = (a.taps - 1) * a.off_step;
+    const int HR = BM + halo;
+    const int xi_total = (HR * CPR + NTHR - 1) / NTHR;
+    const int xps = (xi_total + a.taps - 1) / a.taps;
+    if (xps > (BM * CPR + NTHR - 1) / NTHR || xps > 4) return hipErrorInvalidValue;      // halo too large for the staged-slice scheme
+    if (FUSE2 && (a.N > BN || !a.W2 || a.act == Q3_ACT_SWIGLU)) return hipErrorInvalidValue;
+    const size_t xbuf = (size_t)xi_total * NW * 1024, wring = 3 * round_kb((size_t)BN * BKB) + 1024;   // + a spare KiB for padding DMAs
+    a.nxb = (a.taps <= 3 && round_kb(3 * xbuf) + wring <= 160 * 1024) ? 3 : 2;
+    size_t region0 = a.nxb * xbuf;
+    if (FUSE2) region0 = std::max(region0, (size_t)BM * (a.N * sizeof(TA) + 16));
+    size_t lds = round_kb(region0) + wring;
+    lds = std::max(lds, (size_t)NW * 2 * 16 * (32 * JG + 4) * sizeof(float));    // two wave-private 16-row epilogue slabs per wave
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    const bool seg = a.seg_len > 0;
+    if (a.row_start && !seg) return hipErrorInvalidValue;
+    auto kern = seg ? convgemm_kernel<TA, TO, WAVES_M, WAVES_N, WM, WN, BKB, FUSE2, true>
+                    : convgemm_kernel<TA, TO, WAVES_M, WAVES_N, WM, WN, BKB, FUSE2, false>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    const long long tiles = (long long)((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM);
+    if (tiles > 0x7fffffffLL || a.B > 65535) return hipErrorInvalidValue;
+    dim3 grid((unsigned)tiles, a.B, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(NTHR), lds, s, a);
+    return hipGetLastError();
+}
+
+// tile shapes (rows x columns, K-row bytes, waves)
+enum { SH_256x96 = 0, SH_256x128_K128, SH_128x128_K128, SH_128x128_K64, SH_256x32, SH_F_256x192, SH_F_256x96, SH_F_256x32,
+       SH_256x256_K64, SH_256x192_K64, SH_COUNT };
+
+int pick_shape(const ConvGemmArgs& a, size_t elem) {
+    if (a.W2) {                                   // fused residual unit: one N tile must hold every channel
+        if (a.N <= 32) return SH_F_256x32;
+        if (a.N <= 96) return SH_F_256x96;
+        if (a.N <= 192) return SH_F_256x192;
+        return -1;
+    }
+    const bool wide_k = ((size_t)a.K * elem) % 128 == 0;
+    if (a.N <= 32 && a.act != Q3_ACT_SWIGLU) return SH_256x32;
+    const bool use_96 = (a.act != Q3_ACT_SWIGLU) && (a.N % 128 != 0) && (a.N % 96 == 0) && a.N < 512;
+    if (use_96) return SH_256x96;
+    if (!wide_k) return SH_128x128_K64;
+    // layers of few taps move as many input as weight bytes per step: wider tiles (measured: transposed convs +3..10 %,
+    // k = 7 convs -3 %, which keep 256x128 with 128-byte rows)
+    if (!(q3_convgemm_tuning & 2) && a.act != Q3_ACT_SWIGLU && a.taps <= 3 && (long long)a.B * a.M >= 8192) {
+        if (a.N % 256 == 0) return SH_256x256_K64;
+        if (a.N % 192 == 0 && a.taps > 1) return SH_256x192_K64;
+    }
+    return (q3_convgemm_tuning & 1) ? SH_128x128_K128 : SH_256x128_K128;
+}
+
+template <typename TA, typename TO, bool ALLOW_FUSE>
+hipError_t launch_typed(const ConvGemmArgs& a, hipStream_t s) {
+    switch (pick_shape(a, sizeof(TA))) {
+        case SH_256x96: return launch_cfg<TA, TO, 4, 1, 2, 3, 64, false>(a, s);
+        case SH_256x128_K128: return launch_cfg<TA, TO, 4, 2, 2, 2, 128, false>(a, s);
+        case SH_128x128_K128: return launch_cfg<TA, TO, 2, 2, 2, 2, 128, false>(a, s);
+        case SH_128x128_K64: return launch_cfg<TA, TO, 2, 2, 2, 2, 64, false>(a, s);
+        case SH_256x32: return launch_cfg<TA, TO, 4, 1, 2, 1, 64, false>(a, s);
+        case SH_256x256_K64: return launch_cfg<TA, TO, 4, 2, 2, 4, 64, false>(a, s);
+        case SH_256x192_K64: return launch_cfg<TA, TO, 4, 2, 2, 3, 64, false>(a, s);
+        default: break;
+    }
+    if constexpr (ALLOW_FUSE) {      // the fused form re-reads its input's element type as the residual: same-type pairs only
+        switch (pick_shape(a, sizeof(TA))) {
+            case SH_F_256x192: return launch_cfg<TA, TO, 8, 1, 1, 6, 64, true>(a, s);
+            case SH_F_256x96: return launch_cfg<TA, TO, 4, 1, 2, 3, 64, true>(a, s);
+            case SH_F_256x32: return launch_cfg<TA, TO, 4, 1, 2, 1, 64, true>(a, s);
+            default: break;
+        }
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace
