@@ -399,7 +399,7 @@ int validate_config(q3c_ctx* c) {
         return fail(c, Q3C_ERR_UNSUPPORTED, "codebook_dim must be a multiple of 4 and rvq_out_dim of 8");
     if (k.intermediate_size % 32) return fail(c, Q3C_ERR_UNSUPPORTED, "intermediate_size must be a multiple of 32");
     if (k.decoder_dim % (1 << k.num_upsample_rates)) return bad("decoder_dim not divisible by 2^blocks");
-    if (k.sliding_window < 1 || k.sliding_window > 256) return fail(c, Q3C_ERR_UNSUPPORTED, "sliding_window must be in [1, 256]");
+    if (k.sliding_window < 1 || k.sliding_window > 253) return fail(c, Q3C_ERR_UNSUPPORTED, "sliding_window must be in [1, 253]");
     return 0;
 }
 

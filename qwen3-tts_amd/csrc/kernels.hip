@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(256) swa_attention_kernel(const T* __restrict_
     float* Ks = (float*)smem_att;
     float* Vs = Ks + (size_t)nkmax * ds;
     float* Qs = Vs + (size_t)nkmax * ds;
-    float* Ps = Qs + (size_t)ATT_QT * d + (size_t)wave * 64 * ATT_MAXC;
+    float* Ps = Qs + (size_t)ATT_QT * d + (size_t)wave * 4 * 64 * ATT_MAXC;     // four probability rows per wave
     const int rs = (nh + 2 * nkv) * d;             // qkv row stride
     const T* base = qkv + (size_t)b * Tn * rs;
 
@@ -199,49 +199,79 @@ __global__ void __launch_bounds__(256) swa_attention_kernel(const T* __restrict_
     }
     __syncthreads();
 
-    const int nchunk = (window + 63) >> 6;
-    for (int qi = wave; qi < nq; qi += 4) {
-        const int i = q0 + qi;
-        const int jlo = max(r_min, i - window + 1);
-        const float* qv = Qs + qi * d;
-        float sc[ATT_MAXC];
-        float mx = -INFINITY;
+    // A wave walks its queries four at a time: one key (lane) is scored against four consecutive queries, and one
+    // value element is weighted into four outputs, so every K / V element read from LDS feeds four FMAs.
+    constexpr int QG = 4;
+    const int nchunk = (window + QG - 1 + 63) >> 6;            // the four windows together span window + 3 keys
+    for (int g0 = wave * QG; g0 < nq; g0 += 4 * QG) {
+        const int i0 = q0 + g0;                                // first query row of the group
+        const int jlo = max(r_min, i0 - window + 1);           // first key any of the four may see
+        float sc[QG][ATT_MAXC];
+        float mx[QG];
+#pragma unroll
+        for (int q = 0; q < QG; ++q) mx[q] = -INFINITY;
 #pragma unroll
         for (int c = 0; c < ATT_MAXC; ++c) {
-            sc[c] = -INFINITY;
+#pragma unroll
+            for (int q = 0; q < QG; ++q) sc[q][c] = -INFINITY;
             if (c < nchunk) {
-                int j = jlo + lane + 64 * c;
-                if (j <= i) {
+                const int j = jlo + lane + 64 * c;
+                if (j <= min(i0 + QG - 1, q_hi)) {
                     const float* kr = Ks + (size_t)(j - k_lo) * ds;
-                    float a = 0.f;
-                    for (int e = 0; e < d; ++e) a += qv[e] * kr[e];
-                    sc[c] = a * scale;
+                    float a[QG];
+#pragma unroll
+                    for (int q = 0; q < QG; ++q) a[q] = 0.f;
+                    for (int e = 0; e < d; ++e) {
+                        const float kv = kr[e];
+#pragma unroll
+                        for (int q = 0; q < QG; ++q) a[q] += Qs[min(g0 + q, nq - 1) * d + e] * kv;
+                    }
+#pragma unroll
+                    for (int q = 0; q < QG; ++q) {
+                        const int i = i0 + q;
+                        if (g0 + q < nq && j <= i && j >= max(r_min, i - window + 1)) sc[q][c] = a[q] * scale;
+                    }
                 }
-                mx = fmaxf(mx, sc[c]);
+#pragma unroll
+                for (int q = 0; q < QG; ++q) mx[q] = fmaxf(mx[q], sc[q][c]);
             }
         }
-        mx = wave_max(mx);
-        float sum = 0.f;
+        float inv[QG];
 #pragma unroll
-        for (int c = 0; c < ATT_MAXC; ++c) {
-            float pv = 0.f;
-            if (c < nchunk && sc[c] != -INFINITY) pv = expf(sc[c] - mx);
-            sc[c] = pv;
-            sum += pv;
+        for (int q = 0; q < QG; ++q) {
+            const float m = wave_max(mx[q]);
+            float sum = 0.f;
+#pragma unroll
+            for (int c = 0; c < ATT_MAXC; ++c) {
+                float pv = 0.f;
+                if (c < nchunk && sc[q][c] != -INFINITY) pv = expf(sc[q][c] - m);
+                sc[q][c] = pv;
+                sum += pv;
+            }
+            sum = wave_sum(sum);
+            inv[q] = sum > 0.f ? 1.0f / sum : 0.f;             // a query past the end of the tile has no keys
         }
-        sum = wave_sum(sum);
-        const float inv = 1.0f / sum;
 #pragma unroll
-        for (int c = 0; c < ATT_MAXC; ++c)
-            if (c < nchunk) Ps[lane + 64 * c] = sc[c] * inv;
+        for (int q = 0; q < QG; ++q)
+#pragma unroll
+            for (int c = 0; c < ATT_MAXC; ++c)
+                if (c < nchunk) Ps[q * 64 * ATT_MAXC + lane + 64 * c] = sc[q][c] * inv[q];
         // Ps is private to this wave; LDS ops of one wave complete in order, so no workgroup barrier is needed.
         __builtin_amdgcn_wave_barrier();
-        const int cnt = i - jlo + 1;
+        const int cnt = min(i0 + QG - 1, q_hi) - jlo + 1;
         for (int e = lane; e < d; e += 64) {
-            float a = 0.f;
+            float a[QG];
+#pragma unroll
+            for (int q = 0; q < QG; ++q) a[q] = 0.f;
             const float* vr = Vs + (size_t)(jlo - k_lo) * ds + e;
-            for (int j = 0; j < cnt; ++j) a += Ps[j] * vr[(size_t)j * ds];
-            out[((size_t)b * (Tn - hist) + (i - hist)) * (nh * d) + h * d + e] = q3_from_f32<T>(a);
+            for (int j = 0; j < cnt; ++j) {
+                const float vv = vr[(size_t)j * ds];
+#pragma unroll
+                for (int q = 0; q < QG; ++q) a[q] += Ps[q * 64 * ATT_MAXC + j] * vv;
+            }
+#pragma unroll
+            for (int q = 0; q < QG; ++q)
+                if (g0 + q < nq) out[((size_t)b * (Tn - hist) + (i0 + q - hist)) * (nh * d) + h * d + e] = q3_from_f32<T>(a[q]);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -420,9 +450,9 @@ hipError_t q3_launch_swa_attention(const void* qkv, void* out, const float* cos_
                                    int nkv, int d, int window, int dtype, hipStream_t s, int hist, const int* pos0, int max_pos) {
     if (B == 0 || T == 0) return hipSuccess;
     if (hist < 0 || max_pos < 1) return hipErrorInvalidValue;
-    if (window < 1 || window > 64 * ATT_MAXC || (d & 1) || d > 256) return hipErrorInvalidValue;
+    if (window < 1 || window + 3 > 64 * ATT_MAXC || (d & 1) || d > 256) return hipErrorInvalidValue;
     const int nkmax = ATT_QT + window - 1;
-    size_t lds = ((size_t)2 * nkmax * (d + 1) + (size_t)ATT_QT * d + 4 * 64 * ATT_MAXC) * sizeof(float);
+    size_t lds = ((size_t)2 * nkmax * (d + 1) + (size_t)ATT_QT * d + 4 * 4 * 64 * ATT_MAXC) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     dim3 grid((T + ATT_QT - 1) / ATT_QT, nh, B);
     const float scale = 1.0f / sqrtf((float)d);
