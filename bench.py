@@ -43,12 +43,14 @@ def pmc_traffic(variant: str):
         return None
     ta, to, fused, bm, bn, kb, nw = m.groups()
     mang = {"f32": "f", "bf16": "DF16b"}
-    shapes = {("256", "96", "4"): (4, 1, 2, 3), ("256", "128", "8"): (4, 2, 2, 2), ("128", "128", "4"): (2, 2, 2, 2),
-              ("256", "32", "4"): (4, 1, 2, 1), ("256", "192", "8"): (8, 1, 1, 6)}
-    sh = shapes.get((bm, bn, nw))
+    # (rows, columns, waves, fused) -> the kernel template's wave grid and per-wave tile counts
+    shapes = {("256", "96", "4", False): (4, 1, 2, 3), ("256", "128", "8", False): (4, 2, 2, 2), ("128", "128", "4", False): (2, 2, 2, 2),
+              ("256", "32", "4", False): (4, 1, 2, 1), ("256", "256", "8", False): (4, 2, 2, 4), ("256", "192", "8", False): (4, 2, 2, 3),
+              ("256", "192", "8", True): (8, 1, 1, 6), ("256", "96", "4", True): (4, 1, 2, 3), ("256", "32", "4", True): (4, 1, 2, 1)}
+    sh = shapes.get((bm, bn, nw, bool(fused)))
     if sh is None:
         return None
-    key = f"{mang[ta]}{mang[to]}Li{sh[0]}ELi{sh[1]}ELi{sh[2]}ELi{sh[3]}ELi{kb}ELb{1 if fused else 0}E"
+    key = f"{mang[ta]}{mang[to]}Li{sh[0]}ELi{sh[1]}ELi{sh[2]}ELi{sh[3]}ELi{kb}ELb{1 if fused else 0}ELb0E"
     rec = json.load(open(PMC_TRAFFIC)).get("kernels", {}).get(key)
     return None if rec is None else rec["hbm_bytes_per_launch"]
 
