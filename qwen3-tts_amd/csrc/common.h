@@ -43,6 +43,7 @@ struct ConvGemmArgs {
                                                          // row r >= seg_hist goes to batch item j, row r - seg_hist of Y / Y2 / R
     const void* W2; const float* bias2;                  // [N][N] second contraction, or null
     int nxb;                                             // input buffers in LDS (2 or 3): set by the launcher
+    int tile_order;                                      // 0: N tile slowest, 1: N tile fastest (set by the launcher)
     int debug;                                           // measurement aid: bit 4 = plain (not XCD-grouped) tile order
     const void* zeros;                                   // >= 16 bytes of zeros in device memory (source of out-of-sequence rows)
 };

@@ -130,11 +130,12 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
         const int wg = blockIdx.y * gridDim.x + blockIdx.x;        // dispatch order: x fastest
         const int nwg = gridDim.x * gridDim.y, q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
         const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
-        // Which operand is worth keeping in the XCD's L2 decides the order inside its run of tiles.  Multi-tap layers
-        // re-stream taps x BN x K of weights per block: N tile slowest over the WHOLE grid, so the run walks down the
-        // rows of one or two N tiles.  Single-tap layers have small weights and an input tile as large as the output:
-        // N tile fastest, so the blocks sharing an input tile run side by side and it comes from HBM once.
-        if ((p.taps > 1) != ((p.debug & 32) != 0)) {
+        // Which operand is worth keeping in the XCD's L2 decides the order inside its run of tiles (the launcher picks).
+        // Layers whose weights exceed what an L2 holds beside the streams re-stream taps x BN x K per block: N tile
+        // slowest over the WHOLE grid (tile_order 0), so the run walks down the rows of one or two N tiles.  Layers with
+        // small weights: N tile fastest (1), so the blocks sharing an input tile run side by side and it comes from
+        // HBM once.
+        if ((p.tile_order == 0) != ((p.debug & 32) != 0)) {
             const int m_tiles = gridDim.x / n_tiles, per_n = m_tiles * gridDim.y;
             const int nt = id / per_n, rest = id - nt * per_n;
             b = rest / m_tiles;
@@ -712,6 +713,7 @@ hipError_t launch_cfg(const ConvGemmArgs& a_in, hipStream_t s) {
     if (xps > (BM * CPR + NTHR - 1) / NTHR || xps > 4) return hipErrorInvalidValue;      // halo too large for the staged-slice scheme
     if (FUSE2 && (a.N > BN || !a.W2 || a.act == Q3_ACT_SWIGLU)) return hipErrorInvalidValue;
     const size_t xbuf = (size_t)xi_total * NW * 1024, wring = 3 * round_kb((size_t)BN * BKB) + 1024;   // + a spare KiB for padding DMAs
+    a.tile_order = (long long)a.taps * a.N * a.K * (long long)sizeof(TA) <= (2LL << 20) ? 1 : 0;
     a.nxb = (a.taps <= 3 && round_kb(3 * xbuf) + wring <= 160 * 1024) ? 3 : 2;
     size_t region0 = a.nxb * xbuf;
     if (FUSE2) region0 = std::max(region0, (size_t)BM * (a.N * sizeof(TA) + 16));
