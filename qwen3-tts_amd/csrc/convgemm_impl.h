@@ -552,10 +552,13 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
     static_assert(WN % JG == 0, "slab passes must tile the wave's columns");
     float* slabA = (float*)smem + wave * (2 * SROWS * SLD);
     float* slabB = slabA + SROWS * SLD;
-    const bool swiglu = p.act == Q3_ACT_SWIGLU;
+    // The fused residual unit always has a residual, a consumer's snake, no SwiGLU and 16-byte-aligned rows (the
+    // launcher checks): with those known at compile time its epilogue loops have constant trip counts and no branches.
+    const bool swiglu = !FUSE2 && p.act == Q3_ACT_SWIGLU;
     const int n_out = swiglu ? p.N / 2 : p.N;
-    const bool has_post = p.post_a != nullptr;
-    const bool vec_ok = (p.ldy % EPO == 0) && (!Rb || p.ldr % EPO == 0) && (n_out % EPO == 0);
+    const bool has_post = FUSE2 || p.post_a != nullptr;
+    const bool has_res = FUSE2 || Rb != nullptr;
+    const bool vec_ok = FUSE2 || ((p.ldy % EPO == 0) && (!Rb || p.ldr % EPO == 0) && (n_out % EPO == 0));
     const int first_act = FUSE2 ? Q3_ACT_NONE : p.act;    // FUSE2 consumed the activation before its second contraction
     const float* obias = FUSE2 ? p.bias2 : p.bias;
     // Segmented rows (streams stacked in one row space, each segment = carried rows + new rows): GEMM row m belongs
@@ -579,7 +582,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
             for (int rh = 0; rh < 2; ++rh) {                            // rows 0-15, then 16-31 of the 32-row tile
                 const int mrow0 = m0 + wm * 32 * WM + i * 32 + rh * 16;
                 // phase 0: residual -> slab A
-                if (Rb) {
+                if (has_res) {
                     for (int id = lane; id < SROWS * cprw; id += 64) {
                         const int row = id / cprw, ch = id - row * cprw;
                         const int m = mrow0 + row, n = ncol0 + ch * EPO;
@@ -619,7 +622,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
                                 const int r = rh * 8 + r8;
                                 const int row = (r8 & 3) + 8 * (r8 >> 2) + 4 * half;
                                 float v = q3_silu(acc[i][jg + j][r]) * acc[i][jg + j + 1][r] * sc;
-                                if (Rb) v += slabA[row * SLD + cl];
+                                if (has_res) v += slabA[row * SLD + cl];
                                 slabA[row * SLD + cl] = v;
                             }
                         }
@@ -644,7 +647,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
                             else if (first_act == Q3_ACT_SNAKE) v = q3_snake<TO>(v, ea, eib);
                             else if (first_act == Q3_ACT_CLAMP) v = fminf(1.0f, fmaxf(-1.0f, v));
                             v *= sc;
-                            if (Rb) v += slabA[row * SLD + cl];
+                            if (has_res) v += slabA[row * SLD + cl];
                             if (Y2b) {
                                 slabA[row * SLD + cl] = v;
                                 slabB[row * SLD + cl] = q3_snake<TO>(v, qa, qib);
@@ -711,7 +714,8 @@ hipError_t launch_cfg(const ConvGemmArgs& a_in, hipStream_t s) {
     const int xi_total = (HR * CPR + NTHR - 1) / NTHR;
     const int xps = (xi_total + a.taps - 1) / a.taps;
     if (xps > (BM * CPR + NTHR - 1) / NTHR || xps > 4) return hipErrorInvalidValue;      // halo too large for the staged-slice scheme
-    if (FUSE2 && (a.N > BN || !a.W2 || a.act == Q3_ACT_SWIGLU)) return hipErrorInvalidValue;
+    if (FUSE2 && (a.N > BN || !a.W2 || a.act == Q3_ACT_SWIGLU || !a.R || !a.post_a || a.ldy % 8 || a.ldr % 8 || a.N % 8))
+        return hipErrorInvalidValue;
     const size_t xbuf = (size_t)xi_total * NW * 1024, wring = 3 * round_kb((size_t)BN * BKB) + 1024;   // + a spare KiB for padding DMAs
     a.tile_order = (long long)a.taps * a.N * a.K * (long long)sizeof(TA) <= (2LL << 20) ? 1 : 0;
     a.nxb = (a.taps <= 3 && round_kb(3 * xbuf) + wring <= 160 * 1024) ? 3 : 2;
