@@ -478,12 +478,12 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
                 const bool nv = n < p.N;
                 const float bias = (p.bias && nv) ? p.bias[n] : 0.f;
                 float ea = 0.f, eib = 0.f;
-                if (p.act == Q3_ACT_SNAKE && nv) { ea = p.epi_a[n]; eib = p.epi_invb[n]; }
+                if (nv) { ea = p.epi_a[n]; eib = p.epi_invb[n]; }          // the unit's inner activation is always SnakeBeta
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = wm * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                     float v = acc[i][j][r] + bias;
-                    if (p.act == Q3_ACT_SNAKE) v = q3_snake<TA>(v, ea, eib);
+                    v = q3_snake<TA>(v, ea, eib);
                     if (nv) *(TA*)(Hs + (size_t)row * HLD + n * sizeof(TA)) = q3_from_f32<TA>(v);
                     acc[i][j][r] = 0.f;
                 }
@@ -512,8 +512,8 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
 #pragma unroll
                 for (int i = 0; i < WM; ++i) {
                     // columns past N (a K tail of the last chunk) multiply zero-filled weight columns; read them as zero too
-                    af[i] = (kbyte < p.N * (int)sizeof(TA)) ? *(const uint4*)(Hs + (size_t)(arow0 + i * 32) * HLD + kbyte)
-                                                            : make_uint4(0, 0, 0, 0);
+                    af[i] = (w2_dma || kbyte < p.N * (int)sizeof(TA)) ? *(const uint4*)(Hs + (size_t)(arow0 + i * 32) * HLD + kbyte)
+                                                                      : make_uint4(0, 0, 0, 0);
                 }
 #pragma unroll
                 for (int j = 0; j < WN; ++j) {
@@ -714,7 +714,7 @@ hipError_t launch_cfg(const ConvGemmArgs& a_in, hipStream_t s) {
     const int xi_total = (HR * CPR + NTHR - 1) / NTHR;
     const int xps = (xi_total + a.taps - 1) / a.taps;
     if (xps > (BM * CPR + NTHR - 1) / NTHR || xps > 4) return hipErrorInvalidValue;      // halo too large for the staged-slice scheme
-    if (FUSE2 && (a.N > BN || !a.W2 || a.act == Q3_ACT_SWIGLU || !a.R || !a.post_a || a.ldy % 8 || a.ldr % 8 || a.N % 8))
+    if (FUSE2 && (a.N > BN || !a.W2 || a.act != Q3_ACT_SNAKE || !a.epi_a || !a.epi_invb || !a.R || !a.post_a || a.ldy % 8 || a.ldr % 8 || a.N % 8))
         return hipErrorInvalidValue;
     const size_t xbuf = (size_t)xi_total * NW * 1024, wring = 3 * round_kb((size_t)BN * BKB) + 1024;   // + a spare KiB for padding DMAs
     a.tile_order = (long long)a.taps * a.N * a.K * (long long)sizeof(TA) <= (2LL << 20) ? 1 : 0;
