@@ -50,6 +50,8 @@ def pmc_traffic(variant: str):
     sh = shapes.get((bm, bn, nw, bool(fused)))
     if sh is None:
         return None
+    if (bm, bn, nw, kb) == ("256", "128", "8", "64"):
+        sh = (4, 2, 2, 2)
     key = f"{mang[ta]}{mang[to]}Li{sh[0]}ELi{sh[1]}ELi{sh[2]}ELi{sh[3]}ELi{kb}ELb{1 if fused else 0}ELb0E"
     rec = json.load(open(PMC_TRAFFIC)).get("kernels", {}).get(key)
     return None if rec is None else rec["hbm_bytes_per_launch"]

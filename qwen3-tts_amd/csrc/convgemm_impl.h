@@ -719,6 +719,8 @@ hipError_t launch_cfg(const ConvGemmArgs& a_in, hipStream_t s) {
     const size_t xbuf = (size_t)xi_total * NW * 1024, wring = 3 * round_kb((size_t)BN * BKB) + 1024;   // + a spare KiB for padding DMAs
     a.tile_order = (long long)a.taps * a.N * a.K * (long long)sizeof(TA) <= (2LL << 20) ? 1 : 0;
     a.nxb = (a.taps <= 3 && round_kb(3 * xbuf) + wring <= 160 * 1024) ? 3 : 2;
+    // a third input buffer is not worth a CU's second block
+    if (a.nxb == 3 && a.taps > 1 && round_kb(3 * xbuf) + wring > 80 * 1024 && round_kb(2 * xbuf) + wring <= 80 * 1024) a.nxb = 2;
     size_t region0 = a.nxb * xbuf;
     if (FUSE2) region0 = std::max(region0, (size_t)BM * (a.N * sizeof(TA) + 16));
     size_t lds = round_kb(region0) + wring;
@@ -741,7 +743,7 @@ hipError_t launch_cfg(const ConvGemmArgs& a_in, hipStream_t s) {
 
 // tile shapes (rows x columns, K-row bytes, waves)
 enum { SH_256x96 = 0, SH_256x128_K128, SH_128x128_K128, SH_128x128_K64, SH_256x32, SH_F_256x192, SH_F_256x96, SH_F_256x32,
-       SH_256x256_K64, SH_256x192_K64, SH_COUNT };
+       SH_256x256_K64, SH_256x192_K64, SH_256x128_K64, SH_COUNT };
 
 int pick_shape(const ConvGemmArgs& a, size_t elem) {
     if (a.W2) {                                   // fused residual unit: one N tile must hold every channel
@@ -755,8 +757,11 @@ int pick_shape(const ConvGemmArgs& a, size_t elem) {
     const bool use_96 = (a.act != Q3_ACT_SWIGLU) && (a.N % 128 != 0) && (a.N % 96 == 0) && a.N < 512;
     if (use_96) return SH_256x96;
     if (!wide_k) return SH_128x128_K64;
-    // layers of few taps move as many input as weight bytes per step: wider tiles (measured: transposed convs +3..10 %,
-    // k = 7 convs -3 %, which keep 256x128 with 128-byte rows)
+    // Large layers: 256x128 tiles with 64-byte K rows need 65-73 KB of LDS, so TWO blocks (16 waves) share a CU and one
+    // block's prologue, barriers and epilogue hide under the other's MFMAs (measured against one 129-KB block with
+    // 128-byte rows: k = 7 convs +6..14 %, k = 1 convs +36..49 %, transposed convs +6..19 %).
+    if (!(q3_convgemm_tuning & 2) && a.act != Q3_ACT_SWIGLU && (long long)a.B * a.M >= 65536) return SH_256x128_K64;
+    // smaller layers of few taps move as many input as weight bytes per step: wider tiles
     if (!(q3_convgemm_tuning & 2) && a.act != Q3_ACT_SWIGLU && a.taps <= 3 && (long long)a.B * a.M >= 8192) {
         if (a.N % 256 == 0) return SH_256x256_K64;
         if (a.N % 192 == 0 && a.taps > 1) return SH_256x192_K64;
@@ -774,6 +779,7 @@ hipError_t launch_typed(const ConvGemmArgs& a, hipStream_t s) {
         case SH_256x32: return launch_cfg<TA, TO, 4, 1, 2, 1, 64, false>(a, s);
         case SH_256x256_K64: return launch_cfg<TA, TO, 4, 2, 2, 4, 64, false>(a, s);
         case SH_256x192_K64: return launch_cfg<TA, TO, 4, 2, 2, 3, 64, false>(a, s);
+        case SH_256x128_K64: return launch_cfg<TA, TO, 4, 2, 2, 2, 64, false>(a, s);
         default: break;
     }
     if constexpr (ALLOW_FUSE) {      // the fused form re-reads its input's element type as the residual: same-type pairs only
