@@ -545,7 +545,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
     TO* __restrict__ Y2b = p.Y2 ? (TO*)p.Y2 + (long long)b * p.y2_batch_stride : nullptr;
     const TO* __restrict__ Rb = p.R ? (const TO*)p.R + (long long)b * p.r_batch_stride : nullptr;
     constexpr int EPO = 16 / (int)sizeof(TO);            // output elements per 16-byte piece
-    constexpr int JG = WN <= 4 ? WN : 3;                  // column tiles per slab pass
+    constexpr int JG = WN <= 3 ? WN : 3;                  // column tiles per slab pass
     constexpr int SCOLS = 32 * JG;
     constexpr int SLD = SCOLS + 4;                        // slab row stride in floats (keeps rows 16-byte aligned)
     constexpr int SROWS = 16;
@@ -707,7 +707,7 @@ hipError_t launch_cfg(const ConvGemmArgs& a_in, hipStream_t s) {
     constexpr int NW = WAVES_M * WAVES_N, NTHR = 64 * NW;
     constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
     constexpr int CPR = BKB / 16;
-    constexpr int JG = WN <= 4 ? WN : 3;
+    constexpr int JG = WN <= 3 ? WN : 3;
     ConvGemmArgs a = a_in;
     const int halo = (a.taps - 1) * a.off_step;
     const int HR = BM + halo;
@@ -743,7 +743,7 @@ hipError_t launch_cfg(const ConvGemmArgs& a_in, hipStream_t s) {
 
 // tile shapes (rows x columns, K-row bytes, waves)
 enum { SH_256x96 = 0, SH_256x128_K128, SH_128x128_K128, SH_128x128_K64, SH_256x32, SH_F_256x192, SH_F_256x96, SH_F_256x32,
-       SH_256x256_K64, SH_256x192_K64, SH_256x128_K64, SH_COUNT };
+       SH_256x128_K64, SH_COUNT };
 
 int pick_shape(const ConvGemmArgs& a, size_t elem) {
     if (a.W2) {                                   // fused residual unit: one N tile must hold every channel
@@ -757,15 +757,10 @@ int pick_shape(const ConvGemmArgs& a, size_t elem) {
     const bool use_96 = (a.act != Q3_ACT_SWIGLU) && (a.N % 128 != 0) && (a.N % 96 == 0) && a.N < 512;
     if (use_96) return SH_256x96;
     if (!wide_k) return SH_128x128_K64;
-    // Large layers: 256x128 tiles with 64-byte K rows need 65-73 KB of LDS, so TWO blocks (16 waves) share a CU and one
-    // block's prologue, barriers and epilogue hide under the other's MFMAs (measured against one 129-KB block with
+    // Layers with enough rows to fill the chip: 256x128 tiles with 64-byte K rows need 65-73 KB of LDS, so TWO blocks
+    // (16 waves) share a CU and one block's prologue, barriers and epilogue hide under the other's MFMAs (measured against one 129-KB block with
     // 128-byte rows: k = 7 convs +6..14 %, k = 1 convs +36..49 %, transposed convs +6..19 %).
-    if (!(q3_convgemm_tuning & 2) && a.act != Q3_ACT_SWIGLU && (long long)a.B * a.M >= 65536) return SH_256x128_K64;
-    // smaller layers of few taps move as many input as weight bytes per step: wider tiles
-    if (!(q3_convgemm_tuning & 2) && a.act != Q3_ACT_SWIGLU && a.taps <= 3 && (long long)a.B * a.M >= 8192) {
-        if (a.N % 256 == 0) return SH_256x256_K64;
-        if (a.N % 192 == 0 && a.taps > 1) return SH_256x192_K64;
-    }
+    if (!(q3_convgemm_tuning & 2) && (long long)a.B * a.M >= 8192) return SH_256x128_K64;
     return (q3_convgemm_tuning & 1) ? SH_128x128_K128 : SH_256x128_K128;
 }
 
@@ -777,8 +772,6 @@ hipError_t launch_typed(const ConvGemmArgs& a, hipStream_t s) {
         case SH_128x128_K128: return launch_cfg<TA, TO, 2, 2, 2, 2, 128, false>(a, s);
         case SH_128x128_K64: return launch_cfg<TA, TO, 2, 2, 2, 2, 64, false>(a, s);
         case SH_256x32: return launch_cfg<TA, TO, 4, 1, 2, 1, 64, false>(a, s);
-        case SH_256x256_K64: return launch_cfg<TA, TO, 4, 2, 2, 4, 64, false>(a, s);
-        case SH_256x192_K64: return launch_cfg<TA, TO, 4, 2, 2, 3, 64, false>(a, s);
         case SH_256x128_K64: return launch_cfg<TA, TO, 4, 2, 2, 2, 64, false>(a, s);
         default: break;
     }
