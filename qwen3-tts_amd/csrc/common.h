@@ -86,8 +86,6 @@ hipError_t q3_launch_stream_prep(const int* slots, int S, int capacity, int* pos
                                  const Q3StageStarts& st, int* err_flag, hipStream_t s);
 hipError_t q3_launch_stream_reset(const int* slots, int count, int capacity, void* state, long long slot_stride, int* pos,
                                   int* err_flag, hipStream_t s);
-hipError_t q3_launch_conv_out(const void* x, const float* w /*[k][C]*/, float bias, float* wav, int B, int L, int C, int k,
-                              int dtype, hipStream_t s);
 hipError_t q3_launch_cast_to_f32(const void* x, float* y, long long n, int dtype, hipStream_t s);
 hipError_t q3_launch_cast_from_f32(const float* x, void* y, long long n, int dtype, hipStream_t s);
 hipError_t q3_launch_snake(const void* x, void* y, const float* a, const float* invb, long long rows, int C, int dtype, hipStream_t s);

@@ -1,5 +1,5 @@
 // The decode's bandwidth-bound kernels: RVQ gather-and-sum, mean embedding, RMSNorm, depthwise conv + LayerNorm,
-// sliding-window attention with fused RoPE, the final 1-channel conv + clamp, and small utilities.
+// sliding-window attention with fused RoPE, the stream-state copies, and small utilities.
 // All tensors are channels-last [batch, time, channel].
 #include "common.h"
 #include <algorithm>
@@ -277,43 +277,6 @@ __global__ void __launch_bounds__(256) swa_attention_kernel(const T* __restrict_
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Final conv C -> 1 (kernel k, causal) + clamp(-1, 1).  x already carries the last SnakeBeta.
-// One thread per output sample; its k input rows overlap its neighbours' rows, so the re-reads are L1 hits.
-// ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void __launch_bounds__(256) conv_out_kernel(const T* __restrict__ x, const float* __restrict__ w, float bias,
-                                                       float* __restrict__ wav, int L, int C, int k) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_co[];
-    float* ws = (float*)smem_co;
-    for (int i = threadIdx.x; i < k * C; i += 256) ws[i] = w[i];
-    __syncthreads();
-    const int b = blockIdx.y;
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= L) return;
-    constexpr int EPC = ElemTraits<T>::EPC;
-    const T* xb = x + (size_t)b * L * C;
-    float acc = bias;
-    for (int j = 0; j < k; ++j) {
-        int tt = t - (k - 1) + j;
-        if (tt < 0) continue;
-        const T* xr = xb + (size_t)tt * C;
-        const float* wr = ws + j * C;
-        for (int c = 0; c < C; c += EPC) {
-            uint4 raw = *(const uint4*)(xr + c);
-            if constexpr (EPC == 8) {
-                bf16x8 hv = __builtin_bit_cast(bf16x8, raw);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc += wr[c + e] * (float)hv[e];
-            } else {
-                acc += wr[c] * __builtin_bit_cast(float, raw.x) + wr[c + 1] * __builtin_bit_cast(float, raw.y) +
-                       wr[c + 2] * __builtin_bit_cast(float, raw.z) + wr[c + 3] * __builtin_bit_cast(float, raw.w);
-            }
-        }
-    }
-    wav[(size_t)b * L + t] = fminf(1.0f, fmaxf(-1.0f, acc));
-}
-
 template <typename T>
 __global__ void __launch_bounds__(256) cast_to_f32_kernel(const T* __restrict__ x, float* __restrict__ y, long long n) {
     long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -466,20 +429,6 @@ hipError_t q3_launch_swa_attention(const void* qkv, void* out, const float* cos_
         if (lds > 48 * 1024 && (e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
         hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const float*)qkv, (float*)out, cos_t, sin_t, hist + T, nh, nkv, d, window, scale, hist, pos0, max_pos);
     }
-    return hipGetLastError();
-}
-
-hipError_t q3_launch_conv_out(const void* x, const float* w, float bias, float* wav, int B, int L, int C, int k, int dtype,
-                              hipStream_t s) {
-    if (B == 0 || L <= 0) return hipSuccess;
-    const int epc = dtype == Q3_BF16 ? 8 : 4;
-    if (C % epc) return hipErrorInvalidValue;
-    dim3 grid((L + 255) / 256, B);
-    size_t lds = (size_t)k * C * sizeof(float);
-    if (dtype == Q3_BF16)
-        hipLaunchKernelGGL(conv_out_kernel<bf16>, grid, dim3(256), lds, s, (const bf16*)x, w, bias, wav, L, C, k);
-    else
-        hipLaunchKernelGGL(conv_out_kernel<float>, grid, dim3(256), lds, s, (const float*)x, w, bias, wav, L, C, k);
     return hipGetLastError();
 }
 
