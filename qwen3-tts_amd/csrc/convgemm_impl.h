@@ -112,7 +112,6 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
     constexpr size_t WBUF = round_kb((size_t)BN * BKB);
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per block");
     static_assert(NTHR % CPR == 0, "column chunk of a thread is fixed");
-    static_assert(!FUSE2 || WAVES_N == 1, "the fused second contraction needs whole rows per wave");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -474,7 +473,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
         for (int i = 0; i < WM; ++i)
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
-                const int n = j * 32 + l31;
+                const int n = wn * 32 * WN + j * 32 + l31;      // the h tile is shared through LDS: any wave grid works
                 const bool nv = n < p.N;
                 const float bias = (p.bias && nv) ? p.bias[n] : 0.f;
                 float ea = 0.f, eib = 0.f;
@@ -517,7 +516,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
                 }
 #pragma unroll
                 for (int j = 0; j < WN; ++j) {
-                    int row = j * 32 + l31;
+                    int row = wn * 32 * WN + j * 32 + l31;
                     bfr[j] = *(const uint4*)(ws + (size_t)row * BKB + swz<CPR>(row, c) * 16);
                 }
 #pragma unroll
@@ -777,7 +776,7 @@ hipError_t launch_typed(const ConvGemmArgs& a, hipStream_t s) {
     }
     if constexpr (ALLOW_FUSE) {      // the fused form re-reads its input's element type as the residual: same-type pairs only
         switch (pick_shape(a, sizeof(TA))) {
-            case SH_F_256x192: return launch_cfg<TA, TO, 8, 1, 1, 6, 64, true>(a, s);
+            case SH_F_256x192: return launch_cfg<TA, TO, 4, 2, 2, 3, 64, true>(a, s);    // 2x3 tiles per wave: 5 LDS reads per 6 MFMAs (1x6: 7)
             case SH_F_256x96: return launch_cfg<TA, TO, 4, 1, 2, 3, 64, true>(a, s);
             case SH_F_256x32: return launch_cfg<TA, TO, 4, 1, 2, 1, 64, true>(a, s);
             default: break;
