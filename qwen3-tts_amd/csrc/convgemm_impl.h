@@ -457,6 +457,61 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
 
     const int half = lane >> 5, l31 = lane & 31;
 
+    // ---- output addressing (used by the fused unit's residual prefetch and by the epilogue) ----------------------
+    TO* __restrict__ Yb = (TO*)p.Y + (long long)b * p.y_batch_stride;
+    TO* __restrict__ Y2b = p.Y2 ? (TO*)p.Y2 + (long long)b * p.y2_batch_stride : nullptr;
+    const TO* __restrict__ Rb = p.R ? (const TO*)p.R + (long long)b * p.r_batch_stride : nullptr;
+    constexpr int EPO = 16 / (int)sizeof(TO);            // output elements per 16-byte piece
+    constexpr int JG = WN <= 3 ? WN : 3;                  // column tiles per slab pass
+    constexpr int SCOLS = 32 * JG;
+    constexpr int SLD = SCOLS + 4;                        // slab row stride in floats (keeps rows 16-byte aligned)
+    constexpr int SROWS = 16;
+    static_assert(WN % JG == 0, "slab passes must tile the wave's columns");
+    float* slabA = (float*)smem + wave * (2 * SROWS * SLD);
+    float* slabB = slabA + SROWS * SLD;
+    // The fused residual unit always has a residual, a consumer's snake, no SwiGLU and 16-byte-aligned rows (the
+    // launcher checks): with those known at compile time its epilogue loops have constant trip counts and no branches.
+    const bool swiglu = !FUSE2 && p.act == Q3_ACT_SWIGLU;
+    const int n_out = swiglu ? p.N / 2 : p.N;
+    const bool has_post = FUSE2 || p.post_a != nullptr;
+    const bool has_res = FUSE2 || Rb != nullptr;
+    const bool vec_ok = FUSE2 || ((p.ldy % EPO == 0) && (!Rb || p.ldr % EPO == 0) && (n_out % EPO == 0));
+    const int first_act = FUSE2 ? Q3_ACT_NONE : p.act;    // FUSE2 consumed the activation before its second contraction
+    const float* obias = FUSE2 ? p.bias2 : p.bias;
+    // Segmented rows (streams stacked in one row space, each segment = carried rows + new rows): GEMM row m belongs
+    // to segment m / seg_len and is output row m % seg_len - seg_hist of it; carried rows produce no output.
+    // SEG instantiations serve the streaming decode only; the bulk path compiles to plain row addressing.
+    auto locate = [&](int m, int& bb, int& r) -> bool {
+        bb = 0; r = m;
+        if (m >= p.M) return false;
+        if constexpr (SEG) { bb = m / p.seg_len; r = m - bb * p.seg_len - p.seg_hist; }
+        return r >= 0;
+    };
+
+    // The fused unit fetches the residual rows (the raw stream, rows of this block only) of each epilogue pass one
+    // pass ahead, into registers: the first pass's NOW, so its HBM latency hides under the second contraction, the
+    // others' under the pass before them.  Two register sets alternate.
+    constexpr int CPRW_F = SCOLS / EPO;                         // 16-byte pieces per slab row (no SwiGLU here)
+    constexpr int NPIECE = (SROWS * CPRW_F + 63) / 64;          // pieces per lane and pass
+    constexpr int NPASS = WM * (WN / JG) * 2;
+    uint4 rpre[2][FUSE2 ? NPIECE : 1];
+    auto r_fetch = [&](int pass, uint4* dst) {                  // pass = (i * (WN / JG) + jg / JG) * 2 + rh
+        const int rh = pass & 1, q = pass >> 1, jgi = q % (WN / JG), i = q / (WN / JG);
+#pragma unroll
+        for (int k = 0; k < NPIECE; ++k) {
+            const int id = lane + 64 * k;
+            const int row = id / CPRW_F, ch = id - row * CPRW_F;
+            const int m = m0 + wm * 32 * WM + i * 32 + rh * 16 + row;
+            const int n = n0 + wn * 32 * WN + jgi * JG * 32 + ch * EPO;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            int bb, r;
+            if (id < SROWS * CPRW_F && locate(m, bb, r) && n < n_out)
+                v = *(const uint4*)(Rb + (SEG ? (long long)bb * p.r_batch_stride : 0LL) + (long long)r * p.ldr + n);
+            dst[k] = v;
+        }
+    };
+    if constexpr (FUSE2) r_fetch(0, rpre[0]);
+
     // ---- fused second contraction (k = 1): h = snake(acc + bias) -> LDS -> acc = h . W2^T -------------------------
     if (FUSE2) {
         const int HLD = p.N * (int)sizeof(TA) + 16;                 // padded row stride of the h tile
@@ -540,36 +595,6 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
     //   phase 1  accumulator + bias, activation, scale, + slab A  -> slab A (raw), snake of the consumer -> slab B
     //            (column-wise: the per-channel parameters are two registers per lane)
     //   phase 2  slab A -> Y, slab B -> Y2           (row-wise, 16-byte stores)
-    TO* __restrict__ Yb = (TO*)p.Y + (long long)b * p.y_batch_stride;
-    TO* __restrict__ Y2b = p.Y2 ? (TO*)p.Y2 + (long long)b * p.y2_batch_stride : nullptr;
-    const TO* __restrict__ Rb = p.R ? (const TO*)p.R + (long long)b * p.r_batch_stride : nullptr;
-    constexpr int EPO = 16 / (int)sizeof(TO);            // output elements per 16-byte piece
-    constexpr int JG = WN <= 3 ? WN : 3;                  // column tiles per slab pass
-    constexpr int SCOLS = 32 * JG;
-    constexpr int SLD = SCOLS + 4;                        // slab row stride in floats (keeps rows 16-byte aligned)
-    constexpr int SROWS = 16;
-    static_assert(WN % JG == 0, "slab passes must tile the wave's columns");
-    float* slabA = (float*)smem + wave * (2 * SROWS * SLD);
-    float* slabB = slabA + SROWS * SLD;
-    // The fused residual unit always has a residual, a consumer's snake, no SwiGLU and 16-byte-aligned rows (the
-    // launcher checks): with those known at compile time its epilogue loops have constant trip counts and no branches.
-    const bool swiglu = !FUSE2 && p.act == Q3_ACT_SWIGLU;
-    const int n_out = swiglu ? p.N / 2 : p.N;
-    const bool has_post = FUSE2 || p.post_a != nullptr;
-    const bool has_res = FUSE2 || Rb != nullptr;
-    const bool vec_ok = FUSE2 || ((p.ldy % EPO == 0) && (!Rb || p.ldr % EPO == 0) && (n_out % EPO == 0));
-    const int first_act = FUSE2 ? Q3_ACT_NONE : p.act;    // FUSE2 consumed the activation before its second contraction
-    const float* obias = FUSE2 ? p.bias2 : p.bias;
-    // Segmented rows (streams stacked in one row space, each segment = carried rows + new rows): GEMM row m belongs
-    // to segment m / seg_len and is output row m % seg_len - seg_hist of it; carried rows produce no output.
-    // SEG instantiations serve the streaming decode only; the bulk path compiles to plain row addressing.
-    auto locate = [&](int m, int& bb, int& r) -> bool {
-        bb = 0; r = m;
-        if (m >= p.M) return false;
-        if constexpr (SEG) { bb = m / p.seg_len; r = m - bb * p.seg_len - p.seg_hist; }
-        return r >= 0;
-    };
-
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
 #pragma unroll
@@ -581,7 +606,24 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
             for (int rh = 0; rh < 2; ++rh) {                            // rows 0-15, then 16-31 of the 32-row tile
                 const int mrow0 = m0 + wm * 32 * WM + i * 32 + rh * 16;
                 // phase 0: residual -> slab A
-                if (has_res) {
+                if constexpr (FUSE2) {
+                    const int pidx = (i * (WN / JG) + jg / JG) * 2 + rh;              // compile-time after unrolling
+                    if (pidx + 1 < NPASS) r_fetch(pidx + 1, rpre[(pidx + 1) & 1]);   // next pass's rows: in flight during this pass
+#pragma unroll
+                    for (int k = 0; k < NPIECE; ++k) {
+                        const int id = lane + 64 * k;
+                        if (id < SROWS * CPRW_F) {
+                            const int row = id / CPRW_F, ch = id - row * CPRW_F;
+                            const uint4 raw = rpre[pidx & 1][k];
+                            const TO* rr = (const TO*)&raw;
+                            float* sp = slabA + row * SLD + ch * EPO;
+#pragma unroll
+                            for (int e = 0; e < EPO; e += 4)
+                                *(float4*)(sp + e) = make_float4(q3_to_f32(rr[e]), q3_to_f32(rr[e + 1]), q3_to_f32(rr[e + 2]), q3_to_f32(rr[e + 3]));
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                } else if (has_res) {
                     for (int id = lane; id < SROWS * cprw; id += 64) {
                         const int row = id / cprw, ch = id - row * cprw;
                         const int m = mrow0 + row, n = ncol0 + ch * EPO;
