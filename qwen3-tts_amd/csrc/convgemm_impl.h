@@ -488,6 +488,19 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
         return r >= 0;
     };
 
+    // Per-column epilogue parameters of this lane's WN columns, fetched once (inside the pass loops the stores in between
+    // would force a reload per pass, each with its latency exposed).  SwiGLU pairs columns differently and loads its own.
+    float cbias[WN], csc[WN], cea[WN], ceib[WN], cqa[WN], cqib[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int n = n0 + wn * 32 * WN + j * 32 + (lane & 31);
+        const bool nv = n < n_out && !swiglu;
+        cbias[j] = (obias && nv) ? obias[n] : 0.f;
+        csc[j] = (p.scale && nv && !FUSE2) ? p.scale[n] : 1.f;
+        cea[j] = ceib[j] = cqa[j] = cqib[j] = 0.f;
+        if (first_act == Q3_ACT_SNAKE && nv) { cea[j] = p.epi_a[n]; ceib[j] = p.epi_invb[n]; }
+        if (has_post && nv) { cqa[j] = p.post_a[n]; cqib[j] = p.post_invb[n]; }
+    }
     // The fused unit fetches the residual rows (the raw stream, rows of this block only) of each epilogue pass one
     // pass ahead, into registers: the first pass's NOW, so its HBM latency hides under the second contraction, the
     // others' under the pass before them.  Two register sets alternate.
@@ -672,13 +685,8 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
 #pragma unroll
                     for (int j = 0; j < JG; ++j) {
                         const int cl = j * 32 + l31;
-                        const int n = ncol0 + cl;
-                        const bool nv = n < n_out;
-                        const float bias = (obias && nv) ? obias[n] : 0.f;
-                        const float sc = (p.scale && nv && !FUSE2) ? p.scale[n] : 1.f;
-                        float ea = 0.f, eib = 0.f, qa = 0.f, qib = 0.f;
-                        if (first_act == Q3_ACT_SNAKE && nv) { ea = p.epi_a[n]; eib = p.epi_invb[n]; }
-                        if (has_post && nv) { qa = p.post_a[n]; qib = p.post_invb[n]; }
+                        const float bias = cbias[jg + j], sc = csc[jg + j];
+                        const float ea = cea[jg + j], eib = ceib[jg + j], qa = cqa[jg + j], qib = cqib[jg + j];
 #pragma unroll
                         for (int r8 = 0; r8 < 8; ++r8) {
                             const int r = rh * 8 + r8;
