@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
     const int xi_total = (xpieces + NTHR - 1) / NTHR;
     const int xps = (xi_total + p.taps - 1) / p.taps;   // pieces per thread per step (<= MAX_XPS, host-checked)
     const size_t XBUF = (size_t)xi_total * NW * 1024;          // whole slices: every wave of every slice has its KiB
-    const size_t hs_bytes = (size_t)BM * (p.N * sizeof(TA) + 16);
+    const size_t hs_bytes = (size_t)BM * (BN * sizeof(TA) + 16);
     // single-tap layers (k = 1 convs, linears) use a fresh input tile every step: three buffers, fetched two steps
     // ahead like the weights; multi-tap layers keep a tile for `taps` steps: two buffers, the next one filled in slices
     // layers of two or three taps also get three (when they fit): their chunks are too short to hide an HBM fetch
@@ -476,8 +476,8 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
     const bool has_post = FUSE2 || p.post_a != nullptr;
     const bool has_res = FUSE2 || Rb != nullptr;
     const bool vec_ok = FUSE2 || ((p.ldy % EPO == 0) && (!Rb || p.ldr % EPO == 0) && (n_out % EPO == 0));
-    const int first_act = FUSE2 ? Q3_ACT_NONE : p.act;    // FUSE2 consumed the activation before its second contraction
     const float* obias = FUSE2 ? p.bias2 : p.bias;
+    const int first_act = FUSE2 ? Q3_ACT_NONE : p.act;    // FUSE2 consumed the activation before its second contraction
     // Segmented rows (streams stacked in one row space, each segment = carried rows + new rows): GEMM row m belongs
     // to segment m / seg_len and is output row m % seg_len - seg_hist of it; carried rows produce no output.
     // SEG instantiations serve the streaming decode only; the bulk path compiles to plain row addressing.
@@ -490,24 +490,38 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
 
     // Per-column epilogue parameters of this lane's WN columns, fetched once (inside the pass loops the stores in between
     // would force a reload per pass, each with its latency exposed).  SwiGLU pairs columns differently and loads its own.
+    // The fused unit fetches them after its inner activation (registers are scarce there), under its second contraction.
     float cbias[WN], csc[WN], cea[WN], ceib[WN], cqa[WN], cqib[WN];
+    auto column_params = [&]() {
 #pragma unroll
-    for (int j = 0; j < WN; ++j) {
-        const int n = n0 + wn * 32 * WN + j * 32 + (lane & 31);
-        const bool nv = n < n_out && !swiglu;
-        cbias[j] = (obias && nv) ? obias[n] : 0.f;
-        csc[j] = (p.scale && nv && !FUSE2) ? p.scale[n] : 1.f;
-        cea[j] = ceib[j] = cqa[j] = cqib[j] = 0.f;
-        if (first_act == Q3_ACT_SNAKE && nv) { cea[j] = p.epi_a[n]; ceib[j] = p.epi_invb[n]; }
-        if (has_post && nv) { cqa[j] = p.post_a[n]; cqib[j] = p.post_invb[n]; }
+        for (int j = 0; j < WN; ++j) {
+            const int n = n0 + wn * 32 * WN + j * 32 + (lane & 31);
+            const bool nv = n < n_out && !swiglu;
+            cbias[j] = (obias && nv) ? obias[n] : 0.f;
+            csc[j] = (p.scale && nv && !FUSE2) ? p.scale[n] : 1.f;
+            cea[j] = ceib[j] = cqa[j] = cqib[j] = 0.f;
+            if (first_act == Q3_ACT_SNAKE && nv) { cea[j] = p.epi_a[n]; ceib[j] = p.epi_invb[n]; }
+            if (has_post && nv) { cqa[j] = p.post_a[n]; cqib[j] = p.post_invb[n]; }
+        }
+    };
+    if constexpr (!FUSE2) column_params();
+    float ia[WN], iib[WN], ibias[WN];                           // the fused unit's inner bias and SnakeBeta
+    if constexpr (FUSE2) {
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int n = wn * 32 * WN + j * 32 + (lane & 31);
+            ia[j] = n < p.N ? p.epi_a[n] : 0.f;
+            iib[j] = n < p.N ? p.epi_invb[n] : 0.f;
+            ibias[j] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+        }
     }
     // The fused unit fetches the residual rows (the raw stream, rows of this block only) of each epilogue pass one
     // pass ahead, into registers: the first pass's NOW, so its HBM latency hides under the second contraction, the
-    // others' under the pass before them.  Two register sets alternate.
+    // others' under the pass before them (requested as soon as the registers have been emptied into the slab).
     constexpr int CPRW_F = SCOLS / EPO;                         // 16-byte pieces per slab row (no SwiGLU here)
     constexpr int NPIECE = (SROWS * CPRW_F + 63) / 64;          // pieces per lane and pass
     constexpr int NPASS = WM * (WN / JG) * 2;
-    uint4 rpre[2][FUSE2 ? NPIECE : 1];
+    uint4 rpre[FUSE2 ? NPIECE : 1];
     auto r_fetch = [&](int pass, uint4* dst) {                  // pass = (i * (WN / JG) + jg / JG) * 2 + rh
         const int rh = pass & 1, q = pass >> 1, jgi = q % (WN / JG), i = q / (WN / JG);
 #pragma unroll
@@ -523,11 +537,11 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
             dst[k] = v;
         }
     };
-    if constexpr (FUSE2) r_fetch(0, rpre[0]);
+    if constexpr (FUSE2) r_fetch(0, rpre);
 
     // ---- fused second contraction (k = 1): h = snake(acc + bias) -> LDS -> acc = h . W2^T -------------------------
     if (FUSE2) {
-        const int HLD = p.N * (int)sizeof(TA) + 16;                 // padded row stride of the h tile
+        constexpr int HLD = BN * (int)sizeof(TA) + 16;              // padded row stride of the h tile (compile-time: row offsets are immediates)
         unsigned char* Hs = smem;                                   // overlays the (now idle) input buffers
         const TA* __restrict__ W2 = (const TA*)p.W2;
         const bool w2_dma = (p.N % BK) == 0;      // the h tile is consumed in whole chunks too
@@ -543,20 +557,18 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
             for (int j = 0; j < WN; ++j) {
                 const int n = wn * 32 * WN + j * 32 + l31;      // the h tile is shared through LDS: any wave grid works
                 const bool nv = n < p.N;
-                const float bias = (p.bias && nv) ? p.bias[n] : 0.f;
-                float ea = 0.f, eib = 0.f;
-                if (nv) { ea = p.epi_a[n]; eib = p.epi_invb[n]; }          // the unit's inner activation is always SnakeBeta
+                const float ea = ia[j], eib = iib[j];           // the unit's inner activation is always SnakeBeta
+                unsigned char* hcol = Hs + (size_t)(wm * 32 * WM + 4 * half) * HLD + n * sizeof(TA);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = wm * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    float v = acc[i][j][r] + bias;
-                    v = q3_snake<TA>(v, ea, eib);
-                    if (nv) *(TA*)(Hs + (size_t)row * HLD + n * sizeof(TA)) = q3_from_f32<TA>(v);
+                    const float v = q3_snake<TA>(acc[i][j][r] + ibias[j], ea, eib);
+                    if (nv) *(TA*)(hcol + (i * 32 + (r & 3) + 8 * (r >> 2)) * HLD) = q3_from_f32<TA>(v);
                     acc[i][j][r] = 0.f;
                 }
             }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        column_params();
         const int nkc2 = (p.N + BK - 1) / BK;
         for (int s2 = 0; s2 < nkc2; ++s2) {
             const bool has_next = (s2 + 1) < nkc2;
@@ -621,13 +633,12 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
                 // phase 0: residual -> slab A
                 if constexpr (FUSE2) {
                     const int pidx = (i * (WN / JG) + jg / JG) * 2 + rh;              // compile-time after unrolling
-                    if (pidx + 1 < NPASS) r_fetch(pidx + 1, rpre[(pidx + 1) & 1]);   // next pass's rows: in flight during this pass
 #pragma unroll
                     for (int k = 0; k < NPIECE; ++k) {
                         const int id = lane + 64 * k;
                         if (id < SROWS * CPRW_F) {
                             const int row = id / CPRW_F, ch = id - row * CPRW_F;
-                            const uint4 raw = rpre[pidx & 1][k];
+                            const uint4 raw = rpre[k];
                             const TO* rr = (const TO*)&raw;
                             float* sp = slabA + row * SLD + ch * EPO;
 #pragma unroll
@@ -635,6 +646,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
                                 *(float4*)(sp + e) = make_float4(q3_to_f32(rr[e]), q3_to_f32(rr[e + 1]), q3_to_f32(rr[e + 2]), q3_to_f32(rr[e + 3]));
                         }
                     }
+                    if (pidx + 1 < NPASS) r_fetch(pidx + 1, rpre);      // next pass's rows: in flight during this pass
                     __builtin_amdgcn_wave_barrier();
                 } else if (has_res) {
                     for (int id = lane; id < SROWS * cprw; id += 64) {
@@ -687,22 +699,37 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
                         const int cl = j * 32 + l31;
                         const float bias = cbias[jg + j], sc = csc[jg + j];
                         const float ea = cea[jg + j], eib = ceib[jg + j], qa = cqa[jg + j], qib = cqib[jg + j];
+                        // eight elements at a time: residuals read first, then the math, then the stores, so that the
+                        // eight chains interleave and the run-time choices are made once per group, not per element
+                        float* sa = slabA + (4 * half) * SLD + cl;
+                        float* sb = slabB + (4 * half) * SLD + cl;
+                        float vv[8], rr[8];
+                        if (has_res) {
+#pragma unroll
+                            for (int r8 = 0; r8 < 8; ++r8) rr[r8] = sa[((r8 & 3) + 8 * (r8 >> 2)) * SLD];
+                        }
 #pragma unroll
                         for (int r8 = 0; r8 < 8; ++r8) {
-                            const int r = rh * 8 + r8;
-                            const int row = (r8 & 3) + 8 * (r8 >> 2) + 4 * half;
-                            float v = acc[i][jg + j][r] + bias;
+                            float v = acc[i][jg + j][rh * 8 + r8] + bias;
                             if (first_act == Q3_ACT_GELU) v = q3_gelu(v);
                             else if (first_act == Q3_ACT_SNAKE) v = q3_snake<TO>(v, ea, eib);
                             else if (first_act == Q3_ACT_CLAMP) v = fminf(1.0f, fmaxf(-1.0f, v));
-                            v *= sc;
-                            if (has_res) v += slabA[row * SLD + cl];
-                            if (Y2b) {
-                                slabA[row * SLD + cl] = v;
-                                slabB[row * SLD + cl] = q3_snake<TO>(v, qa, qib);
-                            } else {
-                                slabA[row * SLD + cl] = has_post ? q3_snake<TO>(v, qa, qib) : v;
+                            if (!FUSE2) v *= sc;
+                            if (has_res) v += rr[r8];
+                            vv[r8] = v;
+                        }
+                        if (Y2b) {
+#pragma unroll
+                            for (int r8 = 0; r8 < 8; ++r8) {
+                                sa[((r8 & 3) + 8 * (r8 >> 2)) * SLD] = vv[r8];
+                                sb[((r8 & 3) + 8 * (r8 >> 2)) * SLD] = q3_snake<TO>(vv[r8], qa, qib);
                             }
+                        } else if (has_post) {
+#pragma unroll
+                            for (int r8 = 0; r8 < 8; ++r8) sa[((r8 & 3) + 8 * (r8 >> 2)) * SLD] = q3_snake<TO>(vv[r8], qa, qib);
+                        } else {
+#pragma unroll
+                            for (int r8 = 0; r8 < 8; ++r8) sa[((r8 & 3) + 8 * (r8 >> 2)) * SLD] = vv[r8];
                         }
                     }
                 }
@@ -771,7 +798,7 @@ hipError_t launch_cfg(const ConvGemmArgs& a_in, hipStream_t s) {
     // a third input buffer is not worth a CU's second block
     if (a.nxb == 3 && a.taps > 1 && round_kb(3 * xbuf) + wring > 80 * 1024 && round_kb(2 * xbuf) + wring <= 80 * 1024) a.nxb = 2;
     size_t region0 = a.nxb * xbuf;
-    if (FUSE2) region0 = std::max(region0, (size_t)BM * (a.N * sizeof(TA) + 16));
+    if (FUSE2) region0 = std::max(region0, (size_t)BM * (BN * sizeof(TA) + 16));
     size_t lds = round_kb(region0) + wring;
     lds = std::max(lds, (size_t)NW * 2 * 16 * (32 * JG + 4) * sizeof(float));    // two wave-private 16-row epilogue slabs per wave
     if (lds > 160 * 1024) return hipErrorInvalidValue;
