@@ -162,10 +162,13 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
     // ahead like the weights; multi-tap layers keep a tile for `taps` steps: two buffers, the next one filled in slices
     // layers of two or three taps also get three (when they fit): their chunks are too short to hide an HBM fetch
     const int nxb = p.nxb;
-    const size_t region0 = (FUSE2 && hs_bytes > nxb * XBUF) ? hs_bytes : nxb * XBUF;
+    // LDS map: three weight buffers, then the input buffers.  The fused unit's h tile starts at the THIRD weight buffer
+    // (its second contraction cycles through the first two only) and runs over the input buffers, idle by then.
+    const size_t main_bytes = 3 * WBUF + round_kb(nxb * XBUF);
+    const size_t fuse_bytes = 2 * WBUF + round_kb(hs_bytes);
 
-    unsigned char* Xs0 = smem;                       // the input buffers
-    unsigned char* Ws0 = smem + round_kb(region0);   // three weight buffers
+    unsigned char* Ws0 = smem;                       // three weight buffers
+    unsigned char* Xs0 = smem + 3 * WBUF;            // the input buffers
 
     const TA* __restrict__ Xb = (const TA*)p.X + (long long)b * p.x_batch_stride;
     const TA* __restrict__ Wg = (const TA*)p.W;
@@ -212,8 +215,8 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
     //      to the SOURCE address.  Every call issues a fixed number of DMA instructions per wave (waves with nothing to
     //      fetch aim a padding DMA at a spare KiB) so that the vmcnt bookkeeping needs no per-wave counts.
     const unsigned lds0 = lds_address(smem);
-    const unsigned xs_lds = lds0, ws_lds = lds0 + (unsigned)round_kb(region0);
-    const unsigned spare_lds = ws_lds + 3 * (unsigned)WBUF;
+    const unsigned ws_lds = lds0, xs_lds = lds0 + 3 * (unsigned)WBUF;
+    const unsigned spare_lds = lds0 + (unsigned)((FUSE2 && fuse_bytes > main_bytes) ? fuse_bytes : main_bytes);
     const unsigned char* zero_page = (const unsigned char*)p.zeros;
     constexpr int XROWS_PER_IT = NTHR / CPR;                     // rows one iteration of all waves covers (a multiple of 16)
     const int xrow0 = tid / CPR;
@@ -542,7 +545,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
     // ---- fused second contraction (k = 1): h = snake(acc + bias) -> LDS -> acc = h . W2^T -------------------------
     if (FUSE2) {
         constexpr int HLD = BN * (int)sizeof(TA) + 16;              // padded row stride of the h tile (compile-time: row offsets are immediates)
-        unsigned char* Hs = smem;                                   // overlays the (now idle) input buffers
+        unsigned char* Hs = smem + 2 * WBUF;                        // overlays the third weight buffer and the input buffers, idle now
         const TA* __restrict__ W2 = (const TA*)p.W2;
         const bool w2_dma = (p.N % BK) == 0;      // the h tile is consumed in whole chunks too
         // first W2 tile in flight while h is produced
@@ -792,14 +795,13 @@ hipError_t launch_cfg(const ConvGemmArgs& a_in, hipStream_t s) {
     if (xps > (BM * CPR + NTHR - 1) / NTHR || xps > 4) return hipErrorInvalidValue;      // halo too large for the staged-slice scheme
     if (FUSE2 && (a.N > BN || !a.W2 || a.act != Q3_ACT_SNAKE || !a.epi_a || !a.epi_invb || !a.R || !a.post_a || a.ldy % 8 || a.ldr % 8 || a.N % 8))
         return hipErrorInvalidValue;
-    const size_t xbuf = (size_t)xi_total * NW * 1024, wring = 3 * round_kb((size_t)BN * BKB) + 1024;   // + a spare KiB for padding DMAs
+    const size_t xbuf = (size_t)xi_total * NW * 1024, wbuf = round_kb((size_t)BN * BKB), wring = 3 * wbuf + 1024;   // + a spare KiB for padding DMAs
     a.tile_order = (long long)a.taps * a.N * a.K * (long long)sizeof(TA) <= (2LL << 20) ? 1 : 0;
     a.nxb = (a.taps <= 3 && round_kb(3 * xbuf) + wring <= 160 * 1024) ? 3 : 2;
     // a third input buffer is not worth a CU's second block
     if (a.nxb == 3 && a.taps > 1 && round_kb(3 * xbuf) + wring > 80 * 1024 && round_kb(2 * xbuf) + wring <= 80 * 1024) a.nxb = 2;
-    size_t region0 = a.nxb * xbuf;
-    if (FUSE2) region0 = std::max(region0, (size_t)BM * (BN * sizeof(TA) + 16));
-    size_t lds = round_kb(region0) + wring;
+    size_t lds = wring + round_kb(a.nxb * xbuf);
+    if (FUSE2) lds = std::max(lds, 2 * wbuf + round_kb((size_t)BM * (BN * sizeof(TA) + 16)) + 1024);   // h tile over the third weight buffer and the input buffers
     lds = std::max(lds, (size_t)NW * 2 * 16 * (32 * JG + 4) * sizeof(float));    // two wave-private 16-row epilogue slabs per wave
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const bool seg = a.seg_len > 0;
@@ -819,13 +821,15 @@ hipError_t launch_cfg(const ConvGemmArgs& a_in, hipStream_t s) {
 
 // tile shapes (rows x columns, K-row bytes, waves)
 enum { SH_256x96 = 0, SH_256x128_K128, SH_128x128_K128, SH_128x128_K64, SH_256x32, SH_F_256x192, SH_F_256x96, SH_F_256x32,
-       SH_256x128_K64, SH_COUNT };
+       SH_256x128_K64, SH_F_128x192, SH_COUNT };
 
 int pick_shape(const ConvGemmArgs& a, size_t elem) {
     if (a.W2) {                                   // fused residual unit: one N tile must hold every channel
         if (a.N <= 32) return SH_F_256x32;
         if (a.N <= 96) return SH_F_256x96;
-        if (a.N <= 192) return SH_F_256x192;
+        // 128-row tiles on four waves keep the unit's LDS under 80 KB: two independent blocks per CU, one's h tile and
+        // epilogue under the other's MFMAs, against one 8-wave block in lockstep
+        if (a.N <= 192) return (elem == 2 && !(q3_convgemm_tuning & 4)) ? SH_F_128x192 : SH_F_256x192;
         return -1;
     }
     const bool wide_k = ((size_t)a.K * elem) % 128 == 0;
@@ -854,6 +858,7 @@ hipError_t launch_typed(const ConvGemmArgs& a, hipStream_t s) {
     if constexpr (ALLOW_FUSE) {      // the fused form re-reads its input's element type as the residual: same-type pairs only
         switch (pick_shape(a, sizeof(TA))) {
             case SH_F_256x192: return launch_cfg<TA, TO, 4, 2, 2, 3, 64, true>(a, s);    // 2x3 tiles per wave: 5 LDS reads per 6 MFMAs (1x6: 7)
+            case SH_F_128x192: return launch_cfg<TA, TO, 2, 2, 2, 3, 64, true>(a, s);
             case SH_F_256x96: return launch_cfg<TA, TO, 4, 1, 2, 3, 64, true>(a, s);
             case SH_F_256x32: return launch_cfg<TA, TO, 4, 1, 2, 1, 64, true>(a, s);
             default: break;
