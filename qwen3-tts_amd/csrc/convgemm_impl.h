@@ -98,8 +98,16 @@ __device__ __forceinline__ void block_barrier() {
     asm volatile("" ::: "memory");
 }
 
+// Waves per SIMD the register allocation must leave room for: the 8-wave 64-byte-row shape runs two blocks per CU (four
+// waves per SIMD, 128 registers each); every other shape two waves per SIMD.
+template <int NW, int WM, int WN, int BKB, bool FUSE2> constexpr int waves_per_simd() {
+    return (NW == 8 && !FUSE2 && BKB == 64 && WM * WN <= 4) ? 4 : 2;
+}
+
 template <typename TA, typename TO, int WAVES_M, int WAVES_N, int WM, int WN, int BKB, bool FUSE2, bool SEG>
-__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const ConvGemmArgs p) {
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N)
+__attribute__((amdgpu_waves_per_eu(waves_per_simd<WAVES_M * WAVES_N, WM, WN, BKB, FUSE2>())))
+convgemm_kernel(const ConvGemmArgs p) {
     constexpr int NW = WAVES_M * WAVES_N;            // waves per block
     constexpr int NTHR = 64 * NW;
     constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
@@ -311,12 +319,17 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
         const bool lean1 = p.taps == 1 && nxb == 3 && interior && nsteps >= 3;
         const bool lean2 = p.taps > 1 && nxb == 3 && interior && nkc >= 3;       // multi-tap, input tiles two chunks ahead
         const int x_ahead = lean2 ? 2 : 1;
+        // seven-tap layers (every k = 7 convolution of the decoder) on interior tiles run the unrolled loop below
+        constexpr int TAPS_S = 7;
+        constexpr int XI_S = ((BM + 54) * CPR + NTHR - 1) / NTHR;          // input slices of a 7-tap tile with dilation <= 9
+        const bool unrolled7 = XI_S <= TAPS_S - 2 && p.taps == TAPS_S && nxb == 2 && interior && xi_total == XI_S;
         for (int it = 0; it < xi_total; ++it) x_dma_issue(xs_lds, it, 0);
         w_dma_issue(ws_lds, Wg, wvoff);
         if (nsteps > 1) {
             w_dma_issue(ws_lds + (unsigned)WBUF, Wg + (p.taps > 1 ? tap_stride : (long long)BK), wvoff);
             if (lean1 || lean2) for (int it = 0; it < xi_total; ++it) x_dma_issue(xs_lds + (unsigned)XBUF, it, 1);
-            wait_vmcnt(WITER + ((lean1 || lean2) ? xi_total : 0));
+            if (unrolled7) wait_vmcnt(0);
+            else wait_vmcnt(WITER + ((lean1 || lean2) ? xi_total : 0));
         } else {
             wait_vmcnt(0);
         }
@@ -404,6 +417,57 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
             }
             x_issued = nkc - 1;
         };
+        // Seven taps, interior tile: the seven steps of a chunk unrolled.  Tap, slice and weight-tile bookkeeping are then
+        // compile-time, the buffer rotation is register renaming and every wait is an immediate; the last chunk (no input
+        // tile left to request, weight requests ending two steps early) is a second unrolled copy.  Requests in a step:
+        // the weight tile of step + 2 (spread over the fragment groups), then slice `tap` of the next chunk's input tile.
+        // The wait closing a step lets this step's requests and the previous step's slice stay in flight; the slices end
+        // at tap XI - 1 <= 4, so the chunk's last step finds the whole next tile landed.
+        auto run_unrolled7 = [&]() {
+            constexpr int TAPS = TAPS_S, XI = XI_S < TAPS_S - 2 ? XI_S : TAPS_S - 2;
+            const unsigned xdst_w = xs_lds + (unsigned)wave * 1024u, wdst_w = ws_lds + (unsigned)wave * 1024u;
+            unsigned wo0 = 0, wo1 = (unsigned)WBUF, wo2 = 2 * (unsigned)WBUF;      // weight buffers of step, step + 1, step + 2
+            const TA* wnext = Wg + 2 * tap_stride;                                  // weight tile of step + 2
+            auto one = [&](auto tap_tag, auto last_tag, const unsigned char* xs, unsigned xsn, const TA* xnext) {
+                constexpr int tap = decltype(tap_tag)::value;
+                constexpr bool last = decltype(last_tag)::value;
+                constexpr bool issue_w = !last || tap + 2 < TAPS;
+                constexpr bool issue_x = !last && tap < XI;
+                const unsigned wsn = wdst_w + wo2;
+                compute(xs, Ws0 + wo0, tap * p.off_step, [&](int kg) {
+                    if (issue_w) {
+#pragma unroll
+                        for (int q = 0; q < WITER; ++q)
+                            if ((q < KG ? q : KG - 1) == kg) {
+                                if (WITER * NW * 64 == WPIECES || (q * NW + wave) * 64 < WPIECES) dma16_so(wnext, wvoff[q], wsn + (unsigned)(q * NW) * 1024u);
+                                else dma16_so(zero_page, 0u, spare_lds);
+                            }
+                    }
+                    if (issue_x && kg == KG - 1) dma16_so(xnext + tap * slice_stride, xvoff0, xsn + (unsigned)(tap * NW) * 1024u);
+                });
+                constexpr int in_flight = last ? (issue_w ? WITER : 0)
+                                               : WITER + (tap < XI ? 1 : 0) + ((tap >= 1 && tap - 1 < XI) ? 1 : 0);
+                wait_vmcnt_c<in_flight>();
+                block_barrier();
+                if (issue_w) wnext += ((tap + 3) % TAPS == 0) ? ((long long)BK - (TAPS - 1) * tap_stride) : tap_stride;
+                const unsigned t = wo0; wo0 = wo1; wo1 = wo2; wo2 = t;
+            };
+            auto chunk = [&](auto last_tag, const unsigned char* xs, unsigned xsn, const TA* xnext) {
+                one(std::integral_constant<int, 0>{}, last_tag, xs, xsn, xnext);
+                one(std::integral_constant<int, 1>{}, last_tag, xs, xsn, xnext);
+                one(std::integral_constant<int, 2>{}, last_tag, xs, xsn, xnext);
+                one(std::integral_constant<int, 3>{}, last_tag, xs, xsn, xnext);
+                one(std::integral_constant<int, 4>{}, last_tag, xs, xsn, xnext);
+                one(std::integral_constant<int, 5>{}, last_tag, xs, xsn, xnext);
+                one(std::integral_constant<int, 6>{}, last_tag, xs, xsn, xnext);
+            };
+            int xbs = 0;
+            for (int c = 0; c + 1 < nkc; ++c) {
+                chunk(std::false_type{}, Xs0 + (size_t)xbs * XBUF, xdst_w + (unsigned)((xbs ^ 1) * XBUF), xtile + (long long)(c + 1) * BK);
+                xbs ^= 1;
+            }
+            chunk(std::true_type{}, Xs0 + (size_t)xbs * XBUF, 0u, xtile);
+        };
         auto pipeline = [&](auto xps_tag) {
             constexpr int XPS = decltype(xps_tag)::value;
             for (; step < nsteps; ++step) {
@@ -437,7 +501,8 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) convgemm_kernel(const 
             if (lean1) lean_single(tag, lean_steps); else lean(tag, lean_steps);
             pipeline(tag);
         };
-        switch (xps) {
+        if (unrolled7) run_unrolled7();
+        else switch (xps) {
             case 1: run(std::integral_constant<int, 1>{}); break;
             case 2: run(std::integral_constant<int, 2>{}); break;
             case 3: run(std::integral_constant<int, 3>{}); break;
