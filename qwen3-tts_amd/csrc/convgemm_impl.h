@@ -428,13 +428,14 @@ convgemm_kernel(const ConvGemmArgs p) {
             const unsigned xdst_w = xs_lds + (unsigned)wave * 1024u, wdst_w = ws_lds + (unsigned)wave * 1024u;
             unsigned wo0 = 0, wo1 = (unsigned)WBUF, wo2 = 2 * (unsigned)WBUF;      // weight buffers of step, step + 1, step + 2
             const TA* wnext = Wg + 2 * tap_stride;                                  // weight tile of step + 2
+            int off_step = p.off_step;
             auto one = [&](auto tap_tag, auto last_tag, const unsigned char* xs, unsigned xsn, const TA* xnext) {
                 constexpr int tap = decltype(tap_tag)::value;
                 constexpr bool last = decltype(last_tag)::value;
                 constexpr bool issue_w = !last || tap + 2 < TAPS;
                 constexpr bool issue_x = !last && tap < XI;
                 const unsigned wsn = wdst_w + wo2;
-                compute(xs, Ws0 + wo0, tap * p.off_step, [&](int kg) {
+                compute(xs, Ws0 + wo0, tap * off_step, [&](int kg) {
                     if (issue_w) {
 #pragma unroll
                         for (int q = 0; q < WITER; ++q)
@@ -453,6 +454,9 @@ convgemm_kernel(const ConvGemmArgs p) {
                 const unsigned t = wo0; wo0 = wo1; wo1 = wo2; wo2 = t;
             };
             auto chunk = [&](auto last_tag, const unsigned char* xs, unsigned xsn, const TA* xnext) {
+                // With 128 registers per wave the seven taps' fragment addresses must not be kept across chunks (they
+                // spill, and a reload's wait drains the DMA queue): hide the tap offset's loop invariance from the compiler.
+                if constexpr (waves_per_simd<NW, WM, WN, BKB, FUSE2>() == 4) asm volatile("" : "+s"(off_step));
                 one(std::integral_constant<int, 0>{}, last_tag, xs, xsn, xnext);
                 one(std::integral_constant<int, 1>{}, last_tag, xs, xsn, xnext);
                 one(std::integral_constant<int, 2>{}, last_tag, xs, xsn, xnext);
