@@ -161,6 +161,26 @@ int q3c_causal_tconv1d(const float* x_dev, int32_t batch, int32_t length, int32_
 int q3c_snake_beta(const float* x_dev, int64_t rows, int32_t channels, const float* alpha_host, const float* beta_host,
                    float eps, float* y_dev, void* hip_stream);
 
+/* DecoderResidualUnit (sib :3592-3608): y = x + conv_k1(snake2(conv_k7,dilation(snake1(x)))), x / y [B][L][C], C % 8 == 0;
+ * conv weights [C][C][7] and [C][C][1].  Runs the launch the decode uses for the unit: one fused launch when the
+ * channel count allows (<= 192 in bf16, <= 96 in fp32), otherwise two. */
+int q3c_residual_unit(const float* x_dev, int32_t batch, int32_t length, int32_t channels, int32_t dilation,
+                      const float* alpha1_host, const float* beta1_host, const float* w1_host, const float* b1_host,
+                      const float* alpha2_host, const float* beta2_host, const float* w2_host, const float* b2_host,
+                      float snake_eps, float* y_dev, int32_t precision, void* hip_stream);
+/* ConvNeXtBlock (sib :3231-3263): depthwise causal conv k7 [C][1][7] -> LayerNorm(C, ln_eps) -> Linear(C,4C) -> exact GELU
+ * -> Linear(4C,C) -> gamma -> + x; x / y [B][L][C], C % 8 == 0. */
+int q3c_convnext_block(const float* x_dev, int32_t batch, int32_t length, int32_t channels, const float* dw_weight_host,
+                       const float* dw_bias_host, const float* ln_weight_host, const float* ln_bias_host,
+                       const float* pw1_weight_host, const float* pw1_bias_host, const float* pw2_weight_host,
+                       const float* pw2_bias_host, const float* gamma_host, float ln_eps, float* y_dev, int32_t precision,
+                       void* hip_stream);
+/* Code2WavTransformerModel (sib :3454-3539) with the context's weights: hidden states x [B][T][latent_dim] fp32 ->
+ * y of the same shape (input projection, sliding-window layers, final RMSNorm, output projection; positions start
+ * at 0).  Asynchronous on the stream like q3c_forward; workspace as for q3c_forward(B, T). */
+int q3c_transformer(q3c_ctx* ctx, const float* x_dev, int32_t batch, int32_t frames, float* y_dev, void* workspace_dev,
+                    size_t workspace_bytes, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,7 +64,7 @@ hipError_t q3_launch_mean_embedding(const long long* codes, int B, int Q, int T,
                                     const float* table, void* out, int out_dtype, int* err_flag, hipStream_t s);
 hipError_t q3_launch_rmsnorm(const void* x, const float* w, void* y, long long rows, int H, float eps, int dtype, hipStream_t s);
 // `hist` carried rows sit in front of each item's L rows of x (0: rows before the sequence are zero padding)
-hipError_t q3_launch_dwconv_ln(const void* x, const float* w /*[C][7]*/, const float* b, const float* lnw, const float* lnb,
+hipError_t q3_launch_dwconv_ln(const void* x, const float* w /*[7][C], tap-major*/, const float* b, const float* lnw, const float* lnb,
                                void* y, int B, int L, int C, int k, float eps, int dtype, hipStream_t s, int hist = 0);
 // qkv holds hist + T rows per item, the last T are the queries; pos0[b] (null: 0) is the frame number of query 0
 hipError_t q3_launch_swa_attention(const void* qkv, void* out, const float* cos_t, const float* sin_t, int B, int T,

@@ -375,6 +375,41 @@ int tap_out(q3c_ctx* c, int stage, const void* p, size_t n, hipStream_t s) {
     } while (0)
 #define TRY(expr) do { int _r = (expr); if (_r) return _r; } while (0)
 
+// in_proj -> sliding-window layers -> final RMSNorm -> out_proj on x0 [B,T,latent] held in bufA; bufB is as large, bufC
+// holds q/k/v, the attention output and the MLP activations.  *cur is the result, *other the free one of bufA / bufB.
+int transformer_stack(q3c_ctx* c, int B, int T, void* bufA, void* bufB, char* bufC, hipStream_t s, void** cur_out, void** other_out) {
+    const q3c_config& k = c->cfg;
+    const int dt = c->dtype;
+    const size_t es = esize(dt);
+    const size_t fr = (size_t)B * T;
+    const int H = k.hidden_size;
+    void* x = bufA; void* nrm = bufB;
+    if (k.io_proj) { TRY(gemm(c, c->in_proj, bufA, B, T, bufB, T, dt, GemmOpts{}, s)); x = bufB; nrm = bufA; }
+    const int qd = k.num_attention_heads * k.head_dim, kvd = k.num_key_value_heads * k.head_dim;
+    void* qkv = bufC;
+    void* att = bufC + align_up(fr * (qd + 2 * kvd) * es);
+    void* mlp = (char*)att + align_up(fr * qd * es);
+    for (int l = 0; l < k.num_hidden_layers; ++l) {
+        const Layer& y = c->layers[l];
+        LAUNCH_B(c, s, "rmsnorm", 2 * fr * H * es, q3_launch_rmsnorm(x, y.ln1, nrm, (long long)fr, H, k.rms_norm_eps, dt, s));
+        TRY(gemm(c, y.qkv, nrm, B, T, qkv, T, dt, GemmOpts{}, s));
+        LAUNCH_B(c, s, "swa_attention", fr * (size_t)(2 * qd + 2 * kvd) * es,
+                 q3_launch_swa_attention(qkv, att, c->cos_t, c->sin_t, B, T, k.num_attention_heads, k.num_key_value_heads, k.head_dim,
+                                         k.sliding_window, dt, s));
+        GemmOpts o1; o1.scale = y.ls_attn; o1.R = x;
+        TRY(gemm(c, y.o, att, B, T, x, T, dt, o1, s));
+        LAUNCH_B(c, s, "rmsnorm", 2 * fr * H * es, q3_launch_rmsnorm(x, y.ln2, nrm, (long long)fr, H, k.rms_norm_eps, dt, s));
+        GemmOpts o2; o2.act = Q3_ACT_SWIGLU;
+        TRY(gemm(c, y.gu, nrm, B, T, mlp, T, dt, o2, s));
+        GemmOpts o3; o3.scale = y.ls_mlp; o3.R = x;
+        TRY(gemm(c, y.down, mlp, B, T, x, T, dt, o3, s));
+    }
+    LAUNCH_B(c, s, "rmsnorm", 2 * fr * H * es, q3_launch_rmsnorm(x, c->final_norm, nrm, (long long)fr, H, k.rms_norm_eps, dt, s));
+    if (k.io_proj) { TRY(gemm(c, c->out_proj, nrm, B, T, x, T, dt, GemmOpts{}, s)); *cur_out = x; *other_out = nrm; }
+    else { *cur_out = nrm; *other_out = x; }
+    return 0;
+}
+
 int validate_config(q3c_ctx* c) {
     const q3c_config& k = c->cfg;
     auto bad = [&](const char* m) { return fail(c, Q3C_ERR_INVALID_ARGUMENT, m); };
@@ -923,31 +958,8 @@ int q3c_forward(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, float* w
     TRY(tap_out(c, Q3C_STAGE_TRANSFORMER_IN, bufA, fr * Lt, s));
 
     // ---- transformer ----
-    void* x = bufA; void* nrm = bufB;
-    if (k.io_proj) { TRY(gemm(c, c->in_proj, bufA, B, T, bufB, T, dt, GemmOpts{}, s)); x = bufB; nrm = bufA; }
-    const int qd = k.num_attention_heads * k.head_dim, kvd = k.num_key_value_heads * k.head_dim;
-    void* qkv = bufC;
-    void* att = bufC + align_up(fr * (qd + 2 * kvd) * es);
-    void* mlp = (char*)att + align_up(fr * qd * es);
-    for (int l = 0; l < k.num_hidden_layers; ++l) {
-        const Layer& y = c->layers[l];
-        LAUNCH_B(c, s, "rmsnorm", 2 * fr * H * es, q3_launch_rmsnorm(x, y.ln1, nrm, (long long)fr, H, k.rms_norm_eps, dt, s));
-        TRY(gemm(c, y.qkv, nrm, B, T, qkv, T, dt, GemmOpts{}, s));
-        LAUNCH_B(c, s, "swa_attention", fr * (size_t)(2 * qd + 2 * kvd) * es,
-                 q3_launch_swa_attention(qkv, att, c->cos_t, c->sin_t, B, T, k.num_attention_heads, k.num_key_value_heads, k.head_dim,
-                                         k.sliding_window, dt, s));
-        GemmOpts o1; o1.scale = y.ls_attn; o1.R = x;
-        TRY(gemm(c, y.o, att, B, T, x, T, dt, o1, s));
-        LAUNCH_B(c, s, "rmsnorm", 2 * fr * H * es, q3_launch_rmsnorm(x, y.ln2, nrm, (long long)fr, H, k.rms_norm_eps, dt, s));
-        GemmOpts o2; o2.act = Q3_ACT_SWIGLU;
-        TRY(gemm(c, y.gu, nrm, B, T, mlp, T, dt, o2, s));
-        GemmOpts o3; o3.scale = y.ls_mlp; o3.R = x;
-        TRY(gemm(c, y.down, mlp, B, T, x, T, dt, o3, s));
-    }
-    LAUNCH_B(c, s, "rmsnorm", 2 * fr * H * es, q3_launch_rmsnorm(x, c->final_norm, nrm, (long long)fr, H, k.rms_norm_eps, dt, s));
     void* cur; void* other;
-    if (k.io_proj) { TRY(gemm(c, c->out_proj, nrm, B, T, x, T, dt, GemmOpts{}, s)); cur = x; other = nrm; }
-    else { cur = nrm; other = x; }
+    TRY(transformer_stack(c, B, T, bufA, bufB, bufC, s, &cur, &other));
     TRY(tap_out(c, Q3C_STAGE_TRANSFORMER_OUT, cur, fr * Lt, s));
 
     // ---- upsample stages: transposed conv (k = s = f) then ConvNeXt ----
@@ -1184,6 +1196,128 @@ int q3c_snake_beta(const float* x, int64_t rows, int32_t C, const float* alpha, 
     }
     for (void* p : tmp.allocs) (void)hipFree(p);
     return rc;
+}
+
+
+// x + conv_k1(snake(conv_k7,dilation(snake(x)))) on x [B][L][C]: the decoder's residual unit, through the same launch the
+// decode uses for it (one fused launch when the channel count allows, else two).
+int q3c_residual_unit(const float* x, int32_t B, int32_t L, int32_t C, int32_t dilation, const float* alpha1, const float* beta1,
+                      const float* w1, const float* b1, const float* alpha2, const float* beta2, const float* w2, const float* b2,
+                      float eps, float* y, int32_t precision, void* stream) {
+    if (!x || !y || !alpha1 || !beta1 || !w1 || !b1 || !alpha2 || !beta2 || !w2 || !b2 || B < 1 || L < 1 || C < 8 || C % 8 || dilation < 1)
+        return Q3C_ERR_INVALID_ARGUMENT;
+    q3c_ctx tmp;
+    q3c_ctx* c = &tmp;
+    hipStream_t s = (hipStream_t)stream;
+    const int dt = precision == Q3C_PRECISION_BF16 ? Q3_BF16 : Q3_F32;
+    tmp.dtype = dt;
+    const size_t n = (size_t)B * L * C, es = esize(dt);
+    auto run = [&]() -> int {
+        tmp.staged["c1.weight"] = HostTensor{{C, C, 7}, std::vector<float>(w1, w1 + (size_t)C * C * 7)};
+        tmp.staged["c1.bias"] = HostTensor{{C}, std::vector<float>(b1, b1 + C)};
+        tmp.staged["c2.weight"] = HostTensor{{C, C, 1}, std::vector<float>(w2, w2 + (size_t)C * C)};
+        tmp.staged["c2.bias"] = HostTensor{{C}, std::vector<float>(b2, b2 + C)};
+        GemmW c1, c2;
+        Snake a1, a2, ident;
+        TRY(pack_conv(c, "c1", C, C, 7, dilation, dt, &c1));
+        TRY(pack_conv(c, "c2", C, C, 1, 1, dt, &c2));
+        TRY(pack_snake_host(c, alpha1, beta1, C, eps, &a1));
+        TRY(pack_snake_host(c, alpha2, beta2, C, eps, &a2));
+        // a consumer's SnakeBeta with frequency 0 and gain 0 is the identity: v + 0 * sin^2(0)
+        std::vector<float> zeros((size_t)C, 0.f);
+        ident.C = C;
+        TRY(upload_f32(c, zeros, &ident.a));
+        TRY(upload_f32(c, zeros, &ident.invb));
+        TRY(ensure_zero_page(c));
+        void *raw = nullptr, *sn = nullptr, *h = nullptr, *out = nullptr;
+        TRY(dev_alloc(c, n * es, &raw)); TRY(dev_alloc(c, n * es, &sn)); TRY(dev_alloc(c, n * es, &h)); TRY(dev_alloc(c, n * es, &out));
+        LAUNCH(c, q3_launch_cast_from_f32(x, raw, (long long)n, dt, s));
+        LAUNCH(c, q3_launch_snake(raw, sn, a1.a, a1.invb, (long long)B * L, C, dt, s));
+        if (q3_convgemm_fusable(C, dt)) {
+            GemmOpts g; g.act = Q3_ACT_SNAKE; g.epi = &a2; g.second = &c2; g.R = raw; g.post = &ident; g.Y2 = h;
+            TRY(gemm(c, c1, sn, B, L, out, L, dt, g, s));
+        } else {
+            GemmOpts g1; g1.act = Q3_ACT_SNAKE; g1.epi = &a2;
+            TRY(gemm(c, c1, sn, B, L, h, L, dt, g1, s));
+            GemmOpts g2; g2.R = raw;
+            TRY(gemm(c, c2, h, B, L, out, L, dt, g2, s));
+        }
+        LAUNCH(c, q3_launch_cast_to_f32(out, y, (long long)n, dt, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        return 0;
+    };
+    const int rc = run();
+    if (rc) fprintf(stderr, "q3c_residual_unit: %s\n", tmp.err.c_str());
+    for (void* p : tmp.allocs) (void)hipFree(p);
+    return rc;
+}
+
+// ConvNeXt block on x [B][L][C]: depthwise causal conv k7 -> LayerNorm -> Linear(C,4C) -> GELU -> Linear(4C,C) -> gamma -> + x
+int q3c_convnext_block(const float* x, int32_t B, int32_t L, int32_t C, const float* dw_w, const float* dw_b, const float* ln_w,
+                       const float* ln_b, const float* pw1_w, const float* pw1_b, const float* pw2_w, const float* pw2_b,
+                       const float* gamma, float ln_eps, float* y, int32_t precision, void* stream) {
+    if (!x || !y || !dw_w || !dw_b || !ln_w || !ln_b || !pw1_w || !pw1_b || !pw2_w || !pw2_b || !gamma || B < 1 || L < 1 || C < 8 || C % 8)
+        return Q3C_ERR_INVALID_ARGUMENT;
+    q3c_ctx tmp;
+    q3c_ctx* c = &tmp;
+    hipStream_t s = (hipStream_t)stream;
+    const int dt = precision == Q3C_PRECISION_BF16 ? Q3_BF16 : Q3_F32;
+    tmp.dtype = dt;
+    const size_t n = (size_t)B * L * C, es = esize(dt);
+    auto run = [&]() -> int {
+        tmp.staged["pw1.w"] = HostTensor{{4 * C, C}, std::vector<float>(pw1_w, pw1_w + (size_t)4 * C * C)};
+        tmp.staged["pw1.b"] = HostTensor{{4 * C}, std::vector<float>(pw1_b, pw1_b + 4 * C)};
+        tmp.staged["pw2.w"] = HostTensor{{C, 4 * C}, std::vector<float>(pw2_w, pw2_w + (size_t)4 * C * C)};
+        tmp.staged["pw2.b"] = HostTensor{{C}, std::vector<float>(pw2_b, pw2_b + C)};
+        GemmW pw1, pw2;
+        TRY(pack_linear(c, "pw1.w", "pw1.b", 4 * C, C, dt, &pw1));
+        TRY(pack_linear(c, "pw2.w", "pw2.b", C, 4 * C, dt, &pw2));
+        float *d_dw = nullptr, *d_db = nullptr, *d_lw = nullptr, *d_lb = nullptr, *d_g = nullptr;
+        std::vector<float> dwt((size_t)7 * C);                   // [C][1][7] -> tap-major [7][C]
+        for (int ch = 0; ch < C; ++ch)
+            for (int j = 0; j < 7; ++j) dwt[(size_t)j * C + ch] = dw_w[(size_t)ch * 7 + j];
+        TRY(upload_f32(c, dwt, &d_dw));
+        TRY(upload_f32(c, std::vector<float>(dw_b, dw_b + C), &d_db));
+        TRY(upload_f32(c, std::vector<float>(ln_w, ln_w + C), &d_lw));
+        TRY(upload_f32(c, std::vector<float>(ln_b, ln_b + C), &d_lb));
+        TRY(upload_f32(c, std::vector<float>(gamma, gamma + C), &d_g));
+        TRY(ensure_zero_page(c));
+        void *xi = nullptr, *d = nullptr, *pw = nullptr;
+        TRY(dev_alloc(c, n * es, &xi)); TRY(dev_alloc(c, n * es, &d)); TRY(dev_alloc(c, 4 * n * es, &pw));
+        LAUNCH(c, q3_launch_cast_from_f32(x, xi, (long long)n, dt, s));
+        LAUNCH(c, q3_launch_dwconv_ln(xi, d_dw, d_db, d_lw, d_lb, d, B, L, C, 7, ln_eps, dt, s));
+        GemmOpts g1; g1.act = Q3_ACT_GELU;
+        TRY(gemm(c, pw1, d, B, L, pw, L, dt, g1, s));
+        GemmOpts g2; g2.scale = d_g; g2.R = xi;
+        TRY(gemm(c, pw2, pw, B, L, xi, L, dt, g2, s));
+        LAUNCH(c, q3_launch_cast_to_f32(xi, y, (long long)n, dt, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        return 0;
+    };
+    const int rc = run();
+    if (rc) fprintf(stderr, "q3c_convnext_block: %s\n", tmp.err.c_str());
+    for (void* p : tmp.allocs) (void)hipFree(p);
+    return rc;
+}
+
+// The context's transformer stack alone (in_proj, sliding-window layers, final norm, out_proj) on hidden states
+// x [B][T][latent_dim] in fp32; positions start at 0 as in a chunk of the decode.
+int q3c_transformer(q3c_ctx* c, const float* x, int32_t B, int32_t T, float* y, void* ws, size_t ws_bytes, void* stream) {
+    if (!c) return Q3C_ERR_INVALID_ARGUMENT;
+    if (!c->finalized) return fail(c, Q3C_ERR_STATE, "q3c_finalize has not run");
+    if (!x || !y || !ws || B < 1 || T < 1) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "q3c_transformer: bad argument");
+    if (T > c->cfg.max_positions) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "frames exceed max_positions");
+    if ((uintptr_t)ws & 255) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "workspace must be 256-byte aligned");
+    const Layout lay = make_layout(c, B, T);
+    if (ws_bytes < lay.total) return fail(c, Q3C_ERR_WORKSPACE, "workspace too small: need " + std::to_string(lay.total));
+    hipStream_t s = (hipStream_t)stream;
+    char* base = (char*)ws;
+    const long long n = (long long)B * T * c->cfg.latent_dim;
+    LAUNCH(c, q3_launch_cast_from_f32(x, base + lay.oA, n, c->dtype, s));
+    void *cur, *other;
+    TRY(transformer_stack(c, B, T, base + lay.oA, base + lay.oB, base + lay.oC, s, &cur, &other));
+    LAUNCH(c, q3_launch_cast_to_f32(cur, y, n, c->dtype, s));
+    return 0;
 }
 
 }  // extern "C"

@@ -156,6 +156,19 @@ class Decoder:
                     out[:, :, offsets[j]:offsets[j] + piece.shape[-1]] = piece
         return out
 
+    def transformer(self, hidden: torch.Tensor) -> torch.Tensor:
+        """The transformer stack alone: hidden states [B, T, latent_dim] (fp32) -> the same shape."""
+        x = hidden.to(self.device, torch.float32).contiguous()
+        B, T, D = x.shape
+        if D != self.cfg.latent_dim:
+            raise ValueError(f"Expected {self.cfg.latent_dim} channels, got {D}")
+        y = torch.empty_like(x)
+        ws = self._workspace(B, T)
+        with torch.cuda.device(self.device):
+            self._check(self._lib.q3c_transformer(self._ctx, C.c_void_p(x.data_ptr()), B, T, C.c_void_p(y.data_ptr()),
+                                                  C.c_void_p(ws.data_ptr()), ws.numel() * ws.element_size(), self._stream()))
+        return y
+
     def rvq_dequant(self, codes: torch.Tensor) -> torch.Tensor:
         """Ordered fp32 gather-and-sum of each residual group: codes [B, Q, T] -> [B, T, G, codebook_dim]."""
         codes = self._codes_tensor(codes)
@@ -459,4 +472,45 @@ def snake_beta(x: torch.Tensor, alpha: torch.Tensor, beta: torch.Tensor, eps: fl
                                 eps, C.c_void_p(y.data_ptr()), C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
     if rc:
         raise _lib.Q3cError(rc, "q3c_snake_beta failed")
+    return y
+
+
+def _host(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().cpu().float().contiguous()
+
+
+def residual_unit(x: torch.Tensor, w: dict, prefix: str, dilation: int, eps: float = 1e-9, precision: str = "f32") -> torch.Tensor:
+    """DecoderResidualUnit on x [B, L, C] (device fp32, channels-last); `w` holds the unit's parameters under the
+    torch names (`act1.alpha`, `conv1.conv.weight`, ...) behind `prefix`."""
+    lib = _lib.load()
+    B, L, Cn = x.shape
+    x = x.contiguous().float()
+    names = ["act1.alpha", "act1.beta", "conv1.conv.weight", "conv1.conv.bias", "act2.alpha", "act2.beta", "conv2.conv.weight",
+             "conv2.conv.bias"]
+    hw = [_host(torch.as_tensor(w[prefix + n])) for n in names]
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = lib.q3c_residual_unit(C.c_void_p(x.data_ptr()), B, L, Cn, dilation, *[C.c_void_p(t.data_ptr()) for t in hw], eps,
+                                   C.c_void_p(y.data_ptr()), _lib.PRECISION[precision],
+                                   C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    if rc:
+        raise _lib.Q3cError(rc, "q3c_residual_unit failed")
+    return y
+
+
+def convnext_block(x: torch.Tensor, w: dict, prefix: str, eps: float = 1e-6, precision: str = "f32") -> torch.Tensor:
+    """ConvNeXtBlock on x [B, L, C] (device fp32, channels-last); parameters under the torch names behind `prefix`."""
+    lib = _lib.load()
+    B, L, Cn = x.shape
+    x = x.contiguous().float()
+    names = ["dwconv.conv.weight", "dwconv.conv.bias", "norm.weight", "norm.bias", "pwconv1.weight", "pwconv1.bias",
+             "pwconv2.weight", "pwconv2.bias", "gamma"]
+    hw = [_host(torch.as_tensor(w[prefix + n])) for n in names]
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = lib.q3c_convnext_block(C.c_void_p(x.data_ptr()), B, L, Cn, *[C.c_void_p(t.data_ptr()) for t in hw], eps,
+                                    C.c_void_p(y.data_ptr()), _lib.PRECISION[precision],
+                                    C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    if rc:
+        raise _lib.Q3cError(rc, "q3c_convnext_block failed")
     return y
