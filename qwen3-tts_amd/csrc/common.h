@@ -46,6 +46,8 @@ struct ConvGemmArgs {
     int tile_order;                                      // 0: N tile slowest, 1: N tile fastest (set by the launcher)
     int debug;                                           // measurement aid: bit 4 = plain (not XCD-grouped) tile order
     const void* zeros;                                   // >= 16 bytes of zeros in device memory (source of out-of-sequence rows)
+    long long* timeline; int timeline_slots;             // measurement aid (null normally): every 64th workgroup stores the
+                                                         // clock at its phase boundaries, 8 values per slot
 };
 
 enum Q3Dtype : int { Q3_F32 = 0, Q3_BF16 = 1 };

@@ -34,6 +34,7 @@ extern int q3_convgemm_tuning;
 
 namespace {
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void global_cvoid;
 
@@ -159,6 +160,17 @@ convgemm_kernel(const ConvGemmArgs p) {
         m0 = (tile / n_tiles) * BM;
     }
 
+    // measurement aid: clock at phase boundaries (0 start, 1 first tiles landed, 2 main loop done, 3 h tile written,
+    // 4 second contraction done, 5 epilogue done), every 64th workgroup, wave 0
+    const int tl_wg = blockIdx.y * gridDim.x + blockIdx.x;
+    const bool tl_on = p.timeline != nullptr && (tl_wg & 63) == 0 && (tl_wg >> 6) < p.timeline_slots && wave == 0;
+    auto mark = [&](int k) {
+        if (tl_on) {
+            const long long t = clock64();
+            if (lane == 0) p.timeline[(size_t)(tl_wg >> 6) * 8 + k] = t;
+        }
+    };
+    mark(0);
     const int halo = (p.taps - 1) * p.off_step;
     const int HR = BM + halo;                        // staged input rows
     const int xpieces = HR * CPR;
@@ -334,6 +346,7 @@ convgemm_kernel(const ConvGemmArgs p) {
             wait_vmcnt(0);
         }
         block_barrier();
+        mark(1);
         // pipeline state, shared by the loops below
         int step = 0, kc = 0, tap = 0, wb = 0, xb = 0;           // wb / xb: weight / input buffer of the current step
         int x_issued = (lean1 || lean2) ? 1 : 0;                 // highest chunk whose input tile has been requested
@@ -528,6 +541,7 @@ convgemm_kernel(const ConvGemmArgs p) {
     }
 
     const int half = lane >> 5, l31 = lane & 31;
+    mark(2);
 
     // ---- output addressing (used by the fused unit's residual prefetch and by the epilogue) ----------------------
     TO* __restrict__ Yb = (TO*)p.Y + (long long)b * p.y_batch_stride;
@@ -593,8 +607,31 @@ convgemm_kernel(const ConvGemmArgs p) {
     constexpr int CPRW_F = SCOLS / EPO;                         // 16-byte pieces per slab row (no SwiGLU here)
     constexpr int NPIECE = (SROWS * CPRW_F + 63) / 64;          // pieces per lane and pass
     constexpr int NPASS = WM * (WN / JG) * 2;
-    uint4 rpre[FUSE2 ? NPIECE : 1];
-    auto r_fetch = [&](int pass, uint4* dst) {                  // pass = (i * (WN / JG) + jg / JG) * 2 + rh
+    // A tile with every row inside the sequence and every column inside N (and 16-byte rows) takes the branch-free
+    // epilogue below: its loads and stores are unconditional and counted at compile time, so waiting for the next
+    // pass's residual rows does not also wait for this pass's stores (a skipped store would force vmcnt(0)).
+    constexpr bool FAST_OK = !SEG && (SROWS * CPRW_F) % 64 == 0;
+    const bool full = FAST_OK && vec_ok && !swiglu && (m0 + BM <= p.M) && (n0 + BN <= n_out);
+    // The rows are requested through inline asm: the compiler would otherwise sink the loads to their first use, behind
+    // the stores, and wait for everything.  It therefore does not know that they are pending; an explicit s_waitcnt vmcnt(N) is the wait,
+    // N = the vector-memory operations issued since (the pass's stores, unconditional in this path).
+    u32x4 rpre[NPIECE];
+    auto r_fetch_full = [&](int pass) {
+        const int rh = pass & 1, q = pass >> 1, jgi = q % (WN / JG), i = q / (WN / JG);
+#pragma unroll
+        for (int k = 0; k < NPIECE; ++k) {
+            const int id = lane + 64 * k;
+            const int row = id / CPRW_F, ch = id - row * CPRW_F;
+            const int m = m0 + wm * 32 * WM + i * 32 + rh * 16 + row;
+            const int n = n0 + wn * 32 * WN + jgi * JG * 32 + ch * EPO;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rpre[k]) : "v"(Rb + (long long)m * p.ldr + n) : "memory");
+        }
+    };
+    auto r_pin = [&]() {                                         // after the wait: uses of the rows stay behind it
+#pragma unroll
+        for (int k = 0; k < NPIECE; ++k) asm volatile("" : "+v"(rpre[k]));
+    };
+    auto r_fetch = [&](int pass, u32x4* dst) {                  // pass = (i * (WN / JG) + jg / JG) * 2 + rh
         const int rh = pass & 1, q = pass >> 1, jgi = q % (WN / JG), i = q / (WN / JG);
 #pragma unroll
         for (int k = 0; k < NPIECE; ++k) {
@@ -606,10 +643,10 @@ convgemm_kernel(const ConvGemmArgs p) {
             int bb, r;
             if (id < SROWS * CPRW_F && locate(m, bb, r) && n < n_out)
                 v = *(const uint4*)(Rb + (SEG ? (long long)bb * p.r_batch_stride : 0LL) + (long long)r * p.ldr + n);
-            dst[k] = v;
+            dst[k] = u32x4{v.x, v.y, v.z, v.w};
         }
     };
-    if constexpr (FUSE2) r_fetch(0, rpre);
+    if constexpr (FUSE2) { if (full) r_fetch_full(0); else r_fetch(0, rpre); }
 
     // ---- fused second contraction (k = 1): h = snake(acc + bias) -> LDS -> acc = h . W2^T -------------------------
     if (FUSE2) {
@@ -640,6 +677,7 @@ convgemm_kernel(const ConvGemmArgs p) {
             }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        mark(3);
         column_params();
         const int nkc2 = (p.N + BK - 1) / BK;
         for (int s2 = 0; s2 < nkc2; ++s2) {
@@ -685,6 +723,7 @@ convgemm_kernel(const ConvGemmArgs p) {
         }
     }
 
+    mark(4);
     // ---- epilogue -----------------------------------------------------------------------------------
     // The accumulator layout gives each lane ONE column of 16 rows, while memory wants 16 contiguous bytes per lane.
     // Each wave therefore passes its tile through private fp32 LDS slabs, 16 rows x <= 96 columns at a time:
@@ -692,6 +731,103 @@ convgemm_kernel(const ConvGemmArgs p) {
     //   phase 1  accumulator + bias, activation, scale, + slab A  -> slab A (raw), snake of the consumer -> slab B
     //            (column-wise: the per-channel parameters are two registers per lane)
     //   phase 2  slab A -> Y, slab B -> Y2           (row-wise, 16-byte stores)
+    // Branch-free form for full tiles (see `full` above): same three phases, every load and store unconditional.
+    auto fast_epilogue = [&](auto dual_tag) {
+        constexpr bool DUAL = decltype(dual_tag)::value;
+        if (!FUSE2 && has_res) r_fetch_full(0);
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+#pragma unroll
+            for (int jg = 0; jg < WN; jg += JG) {
+#pragma unroll
+                for (int rh = 0; rh < 2; ++rh) {
+                    const int pidx = (i * (WN / JG) + jg / JG) * 2 + rh;
+                    const int mrow0 = m0 + wm * 32 * WM + i * 32 + rh * 16, ncol0 = n0 + wn * 32 * WN + jg * 32;
+                    if (has_res) {
+                        // since the request: this tile's earlier work and waits (first pass) or one pass's stores
+                        if (pidx == 0) wait_vmcnt_c<0>();
+                        else wait_vmcnt_c<NPIECE * (DUAL ? 2 : 1)>();
+                        r_pin();
+#pragma unroll
+                        for (int k = 0; k < NPIECE; ++k) {
+                            const int id = lane + 64 * k;
+                            const int row = id / CPRW_F, ch = id - row * CPRW_F;
+                            const u32x4 raw = rpre[k];
+                            const TO* rr = (const TO*)&raw;
+                            float* sp = slabA + row * SLD + ch * EPO;
+#pragma unroll
+                            for (int e = 0; e < EPO; e += 4)
+                                *(float4*)(sp + e) = make_float4(q3_to_f32(rr[e]), q3_to_f32(rr[e + 1]), q3_to_f32(rr[e + 2]), q3_to_f32(rr[e + 3]));
+                        }
+                        if (pidx + 1 < NPASS) r_fetch_full(pidx + 1);       // next pass's rows: in flight during this pass
+                        __builtin_amdgcn_wave_barrier();
+                    }
+#pragma unroll
+                    for (int j = 0; j < JG; ++j) {
+                        const int cl = j * 32 + l31;
+                        const float bias = cbias[jg + j], sc = csc[jg + j];
+                        const float ea = cea[jg + j], eib = ceib[jg + j], qa = cqa[jg + j], qib = cqib[jg + j];
+                        float* sa = slabA + (4 * half) * SLD + cl;
+                        float* sb = slabB + (4 * half) * SLD + cl;
+                        float vv[8], rr[8];
+                        if (has_res) {
+#pragma unroll
+                            for (int r8 = 0; r8 < 8; ++r8) rr[r8] = sa[((r8 & 3) + 8 * (r8 >> 2)) * SLD];
+                        }
+#pragma unroll
+                        for (int r8 = 0; r8 < 8; ++r8) {
+                            float v = acc[i][jg + j][rh * 8 + r8] + bias;
+                            if (first_act == Q3_ACT_GELU) v = q3_gelu(v);
+                            else if (first_act == Q3_ACT_SNAKE) v = q3_snake<TO>(v, ea, eib);
+                            else if (first_act == Q3_ACT_CLAMP) v = fminf(1.0f, fmaxf(-1.0f, v));
+                            if (!FUSE2) v *= sc;
+                            if (has_res) v += rr[r8];
+                            vv[r8] = v;
+                        }
+                        if (DUAL) {
+#pragma unroll
+                            for (int r8 = 0; r8 < 8; ++r8) {
+                                sa[((r8 & 3) + 8 * (r8 >> 2)) * SLD] = vv[r8];
+                                sb[((r8 & 3) + 8 * (r8 >> 2)) * SLD] = q3_snake<TO>(vv[r8], qa, qib);
+                            }
+                        } else if (has_post) {
+#pragma unroll
+                            for (int r8 = 0; r8 < 8; ++r8) sa[((r8 & 3) + 8 * (r8 >> 2)) * SLD] = q3_snake<TO>(vv[r8], qa, qib);
+                        } else {
+#pragma unroll
+                            for (int r8 = 0; r8 < 8; ++r8) sa[((r8 & 3) + 8 * (r8 >> 2)) * SLD] = vv[r8];
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int k = 0; k < NPIECE; ++k) {
+                        const int id = lane + 64 * k;
+                        const int row = id / CPRW_F, ch = id - row * CPRW_F;
+                        const long long yo = (long long)(mrow0 + row) * p.ldy + ncol0 + ch * EPO;
+#pragma unroll
+                        for (int which = 0; which < (DUAL ? 2 : 1); ++which) {
+                            const float* sp = (which ? slabB : slabA) + row * SLD + ch * EPO;
+                            uint4 outv;
+                            TO* oo = (TO*)&outv;
+#pragma unroll
+                            for (int e = 0; e < EPO; e += 4) {
+                                const float4 t4 = *(const float4*)(sp + e);
+                                oo[e] = q3_from_f32<TO>(t4.x); oo[e + 1] = q3_from_f32<TO>(t4.y);
+                                oo[e + 2] = q3_from_f32<TO>(t4.z); oo[e + 3] = q3_from_f32<TO>(t4.w);
+                            }
+                            *(uint4*)((which ? Y2b : Yb) + yo) = outv;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+    };
+    if (full) {
+        if (Y2b) fast_epilogue(std::true_type{}); else fast_epilogue(std::false_type{});
+        mark(5);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
 #pragma unroll
@@ -710,7 +846,7 @@ convgemm_kernel(const ConvGemmArgs p) {
                         const int id = lane + 64 * k;
                         if (id < SROWS * CPRW_F) {
                             const int row = id / CPRW_F, ch = id - row * CPRW_F;
-                            const uint4 raw = rpre[k];
+                            const u32x4 raw = rpre[k];
                             const TO* rr = (const TO*)&raw;
                             float* sp = slabA + row * SLD + ch * EPO;
 #pragma unroll
@@ -843,6 +979,7 @@ convgemm_kernel(const ConvGemmArgs p) {
             }
         }
     }
+    mark(5);
 }
 
 // ---- host side ----------------------------------------------------------------------------------------

@@ -165,8 +165,9 @@ class Decoder:
         y = torch.empty_like(x)
         ws = self._workspace(B, T)
         with torch.cuda.device(self.device):
+            base = (ws.data_ptr() + 255) // 256 * 256
             self._check(self._lib.q3c_transformer(self._ctx, C.c_void_p(x.data_ptr()), B, T, C.c_void_p(y.data_ptr()),
-                                                  C.c_void_p(ws.data_ptr()), ws.numel() * ws.element_size(), self._stream()))
+                                                  C.c_void_p(base), ws.numel() - (base - ws.data_ptr()), self._stream()))
         return y
 
     def rvq_dequant(self, codes: torch.Tensor) -> torch.Tensor:
