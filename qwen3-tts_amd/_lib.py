@@ -8,7 +8,8 @@ from typing import Optional
 
 from .config import DecoderConfig, FRONTEND_MEAN_EMBEDDING
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libq3c.so")
+# Q3C_LIB names another build of the library (A/B measurements of two builds on one device)
+LIB_PATH = os.environ.get("Q3C_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libq3c.so")
 Q3C_MAX_STAGES = 8
 
 PRECISION = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
