@@ -164,7 +164,8 @@ __global__ void __launch_bounds__(256) swa_attention_kernel(const T* __restrict_
     const int k_lo = max(r_min, q0 - window + 1);
     const int nk = q_hi - k_lo + 1;
     const int nkmax = ATT_QT + window - 1;
-    const int ds = d + 1;                          // padded row stride: lane = key reads hit distinct banks
+    const int ds = d + 4;                          // padded row stride: rows stay 16-byte aligned, and the 16 lanes a ds_read_b128
+                                                   // serves together (lane = key) cover all 64 banks
     const int half = d >> 1;
     float* Ks = (float*)smem_att;
     float* Vs = Ks + (size_t)nkmax * ds;
@@ -221,10 +222,15 @@ __global__ void __launch_bounds__(256) swa_attention_kernel(const T* __restrict_
                     float a[QG];
 #pragma unroll
                     for (int q = 0; q < QG; ++q) a[q] = 0.f;
-                    for (int e = 0; e < d; ++e) {
-                        const float kv = kr[e];
+                    // four dimensions per LDS read (one b128 of the key row, one broadcast b128 per query); one explicit fma chain in
+                    // dimension order, so the result does not depend on how the compiler would contract products and sums
+                    for (int e = 0; e < d; e += 4) {
+                        const float4 kv = *(const float4*)(kr + e);
 #pragma unroll
-                        for (int q = 0; q < QG; ++q) a[q] += Qs[min(g0 + q, nq - 1) * d + e] * kv;
+                        for (int q = 0; q < QG; ++q) {
+                            const float4 qv = *(const float4*)(Qs + min(g0 + q, nq - 1) * d + e);
+                            a[q] = fmaf(qv.w, kv.w, fmaf(qv.z, kv.z, fmaf(qv.y, kv.y, fmaf(qv.x, kv.x, a[q]))));
+                        }
                     }
 #pragma unroll
                     for (int q = 0; q < QG; ++q) {
@@ -264,10 +270,19 @@ __global__ void __launch_bounds__(256) swa_attention_kernel(const T* __restrict_
 #pragma unroll
             for (int q = 0; q < QG; ++q) a[q] = 0.f;
             const float* vr = Vs + (size_t)(jlo - k_lo) * ds + e;
-            for (int j = 0; j < cnt; ++j) {
+            int j = 0;
+            for (; j + 4 <= cnt; j += 4) {                     // four keys per broadcast read of the probabilities, summed in order
+                const float v0 = vr[(size_t)j * ds], v1 = vr[(size_t)(j + 1) * ds], v2 = vr[(size_t)(j + 2) * ds], v3 = vr[(size_t)(j + 3) * ds];
+#pragma unroll
+                for (int q = 0; q < QG; ++q) {
+                    const float4 pq = *(const float4*)(Ps + q * 64 * ATT_MAXC + j);
+                    a[q] = fmaf(pq.w, v3, fmaf(pq.z, v2, fmaf(pq.y, v1, fmaf(pq.x, v0, a[q]))));
+                }
+            }
+            for (; j < cnt; ++j) {
                 const float vv = vr[(size_t)j * ds];
 #pragma unroll
-                for (int q = 0; q < QG; ++q) a[q] += Ps[q * 64 * ATT_MAXC + j] * vv;
+                for (int q = 0; q < QG; ++q) a[q] = fmaf(Ps[q * 64 * ATT_MAXC + j], vv, a[q]);
             }
 #pragma unroll
             for (int q = 0; q < QG; ++q)
@@ -413,9 +428,9 @@ hipError_t q3_launch_swa_attention(const void* qkv, void* out, const float* cos_
                                    int nkv, int d, int window, int dtype, hipStream_t s, int hist, const int* pos0, int max_pos) {
     if (B == 0 || T == 0) return hipSuccess;
     if (hist < 0 || max_pos < 1) return hipErrorInvalidValue;
-    if (window < 1 || window + 3 > 64 * ATT_MAXC || (d & 1) || d > 256) return hipErrorInvalidValue;
+    if (window < 1 || window + 3 > 64 * ATT_MAXC || (d & 3) || d > 256) return hipErrorInvalidValue;    // rows are read 16 bytes at a time
     const int nkmax = ATT_QT + window - 1;
-    size_t lds = ((size_t)2 * nkmax * (d + 1) + (size_t)ATT_QT * d + 4 * 4 * 64 * ATT_MAXC) * sizeof(float);
+    size_t lds = ((size_t)2 * nkmax * (d + 4) + (size_t)ATT_QT * d + 4 * 4 * 64 * ATT_MAXC) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     dim3 grid((T + ATT_QT - 1) / ATT_QT, nh, B);
     const float scale = 1.0f / sqrtf((float)d);
