@@ -1041,7 +1041,7 @@ int pick_shape(const ConvGemmArgs& a, size_t elem) {
     const bool wide_k = ((size_t)a.K * elem) % 128 == 0;
     if (a.N <= 32 && a.act != Q3_ACT_SWIGLU) return SH_256x32;
     const bool use_96 = (a.act != Q3_ACT_SWIGLU) && (a.N % 128 != 0) && (a.N % 96 == 0) && a.N < 512;
-    if (use_96 && (a.N <= 96 || (long long)a.B * a.M < 8192)) return SH_256x96;     // larger N: more waves per CU beat exact tiling (memory-bound layers)
+    if (use_96 && (a.N <= 96 || (long long)a.B * a.M < 8192 || (q3_convgemm_tuning & 8))) return SH_256x96;     // larger N: more waves per CU beat exact tiling (memory-bound layers)
     if (!wide_k) return SH_128x128_K64;
     // Layers with enough rows to fill the chip: 256x128 tiles with 64-byte K rows need 65-73 KB of LDS, so TWO blocks
     // (16 waves) share a CU and one block's prologue, barriers and epilogue hide under the other's MFMAs (measured against one 129-KB block with

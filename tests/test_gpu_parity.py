@@ -268,3 +268,29 @@ def test_torch_custom_ops_run_the_library():
     got = torch.ops.q3tts.causal_conv1d(x, wt, None, 3, "f32")
     assert max_abs(want, got) <= 2e-5 * max(1.0, float(want.abs().max()))
     torch_ops.unregister_decoder(h)
+
+
+def test_batcher_equals_direct_decode():
+    """Requests from several threads share launch sequences; every caller gets the samples a direct call gives."""
+    import threading
+    from qwen3_tts_amd.batcher import DecodeBatcher
+    cfg = q3.tiny_config()
+    w = q3.synthetic_weights(cfg, seed=6)
+    dec = _decoder(cfg, w, "f32")
+    reqs = [[q3.random_codes(cfg, 1, 2 + (5 * i + 3 * j) % 37, seed=10 * i + j)[0] for j in range(1 + i % 2)] for i in range(6)]
+    want = [dec.decode(r)[0] for r in reqs]
+    got = [None] * len(reqs)
+    with DecodeBatcher(dec, max_wait_ms=300.0) as bat:
+        def work(i):
+            got[i] = bat.decode(reqs[i])[0]
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(len(reqs))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert bat.batches < len(reqs)
+    for a, b in zip(want, got):
+        assert len(a) == len(b)
+        for x, y in zip(a, b):           # another batch mix pads to other lengths: fp32 reductions regroup, nothing more
+            assert x.shape == y.shape and max_abs(x, y) <= 1e-5
+

@@ -275,3 +275,68 @@ def test_torch_ops_are_registered_with_shape_functions():
     with pytest.raises(NotImplementedError):                      # real CPU tensors: there is no CPU kernel
         torch.ops.q3tts.rvq_dequant(torch.zeros((1, cfg.num_quantizers, 3), dtype=torch.int64), h)
     torch_ops.unregister_decoder(h)
+
+
+# ---- cross-request batching (host logic only: a stand-in decoder) ----------------------------------------
+class _CountingDecoder:
+    """`Decoder.decode`'s contract without a GPU: waveform i = per-frame sum of utterance i's codes."""
+
+    def __init__(self, cfg):
+        from qwen3_tts_amd.decoder import Decoder
+        self.cfg = cfg
+        self.calls = []
+        self._norm = Decoder._normalize_items
+
+    def _normalize_items(self, encoded):
+        return self._norm(self, encoded)
+
+    def decode(self, encoded):
+        items = self._normalize_items(encoded)
+        self.calls.append(len(items))
+        for c in items:
+            if int(c.max()) >= self.cfg.codebook_size:
+                raise IndexError("code out of range")
+        return [c.float().sum(0).numpy() for c in items], 24000
+
+
+def test_batcher_groups_concurrent_requests_and_returns_each_its_own():
+    import threading
+    from qwen3_tts_amd.batcher import DecodeBatcher
+    cfg = q3.tiny_config()
+    dec = _CountingDecoder(cfg)
+    reqs = [[q3.random_codes(cfg, 1, 3 + (7 * i + j) % 11, seed=100 * i + j)[0] for j in range(1 + i % 3)] for i in range(12)]
+    results = [None] * len(reqs)
+    with DecodeBatcher(dec, max_wait_ms=200.0) as bat:
+        def work(i):
+            results[i] = bat.decode(reqs[i])
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(len(reqs))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert bat.requests == len(reqs) and bat.batches < len(reqs)          # requests shared launches
+    assert sum(dec.calls) == sum(len(r) for r in reqs)
+    for i, r in enumerate(reqs):
+        wavs, sr = results[i]
+        assert sr == 24000 and len(wavs) == len(r)
+        for w, c in zip(wavs, r):
+            assert np.array_equal(w, c.float().sum(0).numpy())
+
+
+def test_batcher_errors_stay_with_their_request():
+    from qwen3_tts_amd.batcher import DecodeBatcher
+    cfg = q3.tiny_config()
+    dec = _CountingDecoder(cfg)
+    good = q3.random_codes(cfg, 1, 5, seed=1)[0]
+    bad = good.clone()
+    bad[0, 2] = cfg.codebook_size                                   # found only by the decode itself
+    with DecodeBatcher(dec, max_wait_ms=100.0) as bat:
+        with pytest.raises(ValueError):                             # wrong code-book count: rejected in the caller's thread
+            bat.submit(torch.zeros((cfg.num_quantizers + 1, cfg.num_quantizers + 5), dtype=torch.int64))
+        f1, f2, f3 = bat.submit(good), bat.submit(bad), bat.submit([good, good])
+        assert np.array_equal(f1.result()[0][0], good.float().sum(0).numpy())
+        with pytest.raises(IndexError):
+            f2.result()
+        assert len(f3.result()[0]) == 2
+    with pytest.raises(RuntimeError):
+        bat.submit(good)
