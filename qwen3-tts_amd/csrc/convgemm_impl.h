@@ -168,6 +168,11 @@ convgemm_kernel(const ConvGemmArgs p) {
         if (tl_on) {
             const long long t = clock64();
             if (lane == 0) p.timeline[(size_t)(tl_wg >> 6) * 8 + k] = t;
+            // slots 6 / 7: the constant 100 MHz counter at start and end, which gives the shader clock the tile ran at
+            if (k == 0 || k == 5) {
+                const long long w = wall_clock64();
+                if (lane == 0) p.timeline[(size_t)(tl_wg >> 6) * 8 + (k == 0 ? 6 : 7)] = w;
+            }
         }
     };
     mark(0);
@@ -1032,7 +1037,7 @@ enum { SH_256x96 = 0, SH_256x128_K128, SH_128x128_K128, SH_128x128_K64, SH_256x3
 int pick_shape(const ConvGemmArgs& a, size_t elem) {
     if (a.W2) {                                   // fused residual unit: one N tile must hold every channel
         if (a.N <= 32) return SH_F_256x32;
-        if (a.N <= 96) return SH_F_256x96;
+        if (a.N <= 96) return SH_F_256x96;       // (128-row tiles, three blocks per CU: measured 9 % slower)
         // 128-row tiles on four waves keep the unit's LDS under 80 KB: two independent blocks per CU, one's h tile and
         // epilogue under the other's MFMAs, against one 8-wave block in lockstep
         if (a.N <= 192) return (elem == 2 && !(q3_convgemm_tuning & 4)) ? SH_F_128x192 : SH_F_256x192;

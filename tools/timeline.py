@@ -26,7 +26,10 @@ def report(name, fused):
     d = (t[:, 1:6] - t[:, 0:5]).double()
     tot = (t[:, 5] - t[:, 0]).double()
     names = ["prologue (first tiles)", "main loop", "inner activation -> h tile", "second contraction", "epilogue"]
-    print(f"{name}: {t.shape[0]} sampled tiles, {tot.mean():.0f} cycles per tile (p10 {tot.quantile(0.1):.0f}, p90 {tot.quantile(0.9):.0f})")
+    wall = (t[:, 7] - t[:, 6]).double()               # 100 MHz ticks
+    mhz = (tot.sum() / wall.sum() * 100.0).item() if wall.sum() > 0 else float("nan")
+    print(f"{name}: {t.shape[0]} sampled tiles, {tot.mean():.0f} cycles per tile (p10 {tot.quantile(0.1):.0f}, p90 {tot.quantile(0.9):.0f}), "
+          f"shader clock {mhz:.0f} MHz")
     for i, n in enumerate(names):
         if not fused and i in (2, 3):
             continue
@@ -57,8 +60,20 @@ def conv(cin, cout, k, dil, B, L):
     report(f"conv k{k} d{dil} {cin}->{cout}, {B} x {L} rows", False)
 
 
+def tconv(cin, cout, stride, B, L):
+    w = torch.randn(cin, cout, 2 * stride, generator=g) * (2 * cin) ** -0.5
+    x = torch.randn(B, L, cin, device="cuda")
+    D.causal_trans_conv1d(x, w, torch.zeros(cout), stride, "bf16")
+    lib.q3c_debug_set_timeline(C.c_void_p(buf.data_ptr()), SLOTS)
+    D.causal_trans_conv1d(x, w, torch.zeros(cout), stride, "bf16")
+    lib.q3c_debug_set_timeline(None, 0)
+    report(f"transposed conv k{2 * stride} s{stride} {cin}->{cout} (single output), {B} x {L} rows", False)
+
+
 unit(96, 1, 16, 575445)
 unit(96, 9, 16, 575445)
 unit(192, 3, 16, 191815)
 conv(384, 384, 7, 3, 16, 47955)
 conv(384, 384, 1, 1, 16, 47955)
+tconv(384, 192, 4, 16, 47955)
+tconv(192, 96, 3, 16, 191816)
