@@ -100,6 +100,10 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         if name not in ("q3c_destroy", "q3c_last_error", "q3c_version", "q3c_stream_pool_destroy"):
             fn.restype = C.c_int
+    if os.environ.get("Q3C_TUNING"):          # measurement aid: A/B switches of the contraction kernel's shape choice
+        lib.q3c_debug_set_tuning.argtypes = [C.c_int]
+        lib.q3c_debug_set_tuning.restype = None
+        lib.q3c_debug_set_tuning(int(os.environ["Q3C_TUNING"]))
     _lib = lib
     return lib
 

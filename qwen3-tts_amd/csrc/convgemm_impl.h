@@ -988,8 +988,10 @@ convgemm_kernel(const ConvGemmArgs p) {
 }
 
 // ---- host side ----------------------------------------------------------------------------------------
-// A/B switches for measurements, defined in convgemm.hip: bit 0 = 4-wave 128x128 tiles, bit 1 = no wide tiles;
-// bits 8.. are handed to the kernel as ConvGemmArgs::debug
+// A/B switches for measurements (q3_convgemm_tuning, defined in convgemm.hip): bit 0 flips the 128- / 256-row choice for
+// layers of few rows, bit 1 = one block per CU (128-byte K rows) for large layers, bit 2 = the fused 192-channel unit on
+// 256-row tiles, bit 3 = exact 96-column tiling for the 288-column transposed conv; bits 8.. go to the kernel as
+// ConvGemmArgs::debug
 
 
 template <typename TA, typename TO, int WAVES_M, int WAVES_N, int WM, int WN, int BKB, bool FUSE2>
@@ -1052,7 +1054,11 @@ int pick_shape(const ConvGemmArgs& a, size_t elem) {
     // (16 waves) share a CU and one block's prologue, barriers and epilogue hide under the other's MFMAs (measured against one 129-KB block with
     // 128-byte rows: k = 7 convs +6..14 %, k = 1 convs +36..49 %, transposed convs +6..19 %).
     if (!(q3_convgemm_tuning & 2) && (long long)a.B * a.M >= 8192) return SH_256x128_K64;
-    return (q3_convgemm_tuning & 1) ? SH_128x128_K128 : SH_256x128_K128;
+    // Few rows (a streaming push, a short utterance): 128-row tiles on four waves double the number of blocks when
+    // 256-row tiles would leave most of the 256 CUs idle (256 streams x 1 frame: push 5.75 -> 5.46 ms)
+    const long long tiles256 = (((long long)a.B * a.M + 255) / 256) * ((a.N + 127) / 128);
+    const bool small = tiles256 < 512;
+    return (small != ((q3_convgemm_tuning & 1) != 0)) ? SH_128x128_K128 : SH_256x128_K128;
 }
 
 template <typename TA, typename TO, bool ALLOW_FUSE>

@@ -4,7 +4,7 @@
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/refresh
-mkdir -p $O && cd $R || exit 1
+rm -rf $O; mkdir -p $O && cd $R || exit 1
 export TMPDIR=/tmp
 timeout -k 10 300 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > $O/pytest_gpu.txt 2>&1 &&
 timeout -k 10 400 python bench.py > $O/bench.json 2> $O/bench.err &&
