@@ -181,7 +181,11 @@ convgemm_kernel(const ConvGemmArgs p) {
     const int xpieces = HR * CPR;
     const int xi_total = (xpieces + NTHR - 1) / NTHR;
     const int xps = (xi_total + p.taps - 1) / p.taps;   // pieces per thread per step (<= MAX_XPS, host-checked)
-    const size_t XBUF = (size_t)xi_total * NW * 1024;          // whole slices: every wave of every slice has its KiB
+    // An input buffer holds the KiB-sized wave DMAs that carry staged rows; the last slice is usually partial (a two-tap
+    // layer's third slice carries ONE row), and waves whose KiB of it would lie past the staged rows aim at the spare KiB.
+    const int x_kb = (xpieces + 63) / 64;
+    const size_t XBUF = (size_t)x_kb * 1024;
+    const bool last_slice_real = (xi_total - 1) * NW + wave < x_kb;       // this wave's part of the last slice holds staged rows
     const size_t hs_bytes = (size_t)BM * (BN * sizeof(TA) + 16);
     // single-tap layers (k = 1 convs, linears) use a fresh input tile every step: three buffers, fetched two steps
     // ahead like the weights; multi-tap layers keep a tile for `taps` steps: two buffers, the next one filled in slices
@@ -252,7 +256,7 @@ convgemm_kernel(const ConvGemmArgs p) {
     // input rows [it*XROWS_PER_IT ...) of chunk kc -> buffer at xs; rows outside the sequence come from the zero page
     auto x_dma_issue = [&](unsigned xs, int it, int kc) {
         const int slot = it * NW + wave;
-        if (it >= xi_total) { dma16_so(zero_page, 0u, spare_lds); return; }     // a step with no slice left: padding DMA
+        if (it >= xi_total || slot >= x_kb) { dma16_so(zero_page, 0u, spare_lds); return; }     // nothing (left) to stage: padding DMA
         const TA* sbase = xtile + ((long long)it * XROWS_PER_IT * p.ldx + kc * BK);
         if (interior) {
             dma16_so(sbase, xvoff0, xs + (unsigned)slot * 1024u);
@@ -390,7 +394,8 @@ convgemm_kernel(const ConvGemmArgs p) {
                     if (kg == KG - 1) {
 #pragma unroll
                         for (int i = 0; i < XPS; ++i) {
-                            if (xit + i < xi_total) dma16_so(xsrc + i * slice_stride, xvoff0, xsn + (unsigned)((xit + i) * NW) * 1024u);
+                            if (xit + i < xi_total - 1 || (xit + i == xi_total - 1 && last_slice_real))
+                                dma16_so(xsrc + i * slice_stride, xvoff0, xsn + (unsigned)((xit + i) * NW) * 1024u);
                             else dma16_so(zero_page, 0u, spare_lds);
                         }
                     }
@@ -462,7 +467,10 @@ convgemm_kernel(const ConvGemmArgs p) {
                                 else dma16_so(zero_page, 0u, spare_lds);
                             }
                     }
-                    if (issue_x && kg == KG - 1) dma16_so(xnext + tap * slice_stride, xvoff0, xsn + (unsigned)(tap * NW) * 1024u);
+                    if (issue_x && kg == KG - 1) {
+                        if (tap < XI - 1 || last_slice_real) dma16_so(xnext + tap * slice_stride, xvoff0, xsn + (unsigned)(tap * NW) * 1024u);
+                        else dma16_so(zero_page, 0u, spare_lds);
+                    }
                 });
                 constexpr int in_flight = last ? (issue_w ? WITER : 0)
                                                : WITER + (tap < XI ? 1 : 0) + ((tap >= 1 && tap - 1 < XI) ? 1 : 0);
@@ -1008,7 +1016,7 @@ hipError_t launch_cfg(const ConvGemmArgs& a_in, hipStream_t s) {
     if (xps > (BM * CPR + NTHR - 1) / NTHR || xps > 4) return hipErrorInvalidValue;      // halo too large for the staged-slice scheme
     if (FUSE2 && (a.N > BN || !a.W2 || a.act != Q3_ACT_SNAKE || !a.epi_a || !a.epi_invb || !a.R || !a.post_a || a.ldy % 8 || a.ldr % 8 || a.N % 8))
         return hipErrorInvalidValue;
-    const size_t xbuf = (size_t)xi_total * NW * 1024, wbuf = round_kb((size_t)BN * BKB), wring = 3 * wbuf + 1024;   // + a spare KiB for padding DMAs
+    const size_t xbuf = (size_t)((HR * CPR + 63) / 64) * 1024, wbuf = round_kb((size_t)BN * BKB), wring = 3 * wbuf + 1024;   // + a spare KiB for padding DMAs
     a.tile_order = (long long)a.taps * a.N * a.K * (long long)sizeof(TA) <= (2LL << 20) ? 1 : 0;
     a.nxb = (a.taps <= 3 && round_kb(3 * xbuf) + wring <= 160 * 1024) ? 3 : 2;
     // a third input buffer is not worth a CU's second block
