@@ -344,6 +344,10 @@ convgemm_kernel(const ConvGemmArgs p) {
         constexpr int TAPS_S = 7;
         constexpr int XI_S = ((BM + 54) * CPR + NTHR - 1) / NTHR;          // input slices of a 7-tap tile with dilation <= 9
         const bool unrolled7 = XI_S <= TAPS_S - 2 && p.taps == TAPS_S && nxb == 2 && interior && xi_total == XI_S;
+        // one- and two-tap layers with three input buffers (run_static below)
+        constexpr int XI_1 = (BM * CPR + NTHR - 1) / NTHR, XI_2 = ((BM + 1) * CPR + NTHR - 1) / NTHR;
+        const bool static1 = lean1 && xi_total == XI_1;
+        const bool static2 = lean2 && p.taps == 2 && p.off_step == 1 && xi_total == XI_2;
         for (int it = 0; it < xi_total; ++it) x_dma_issue(xs_lds, it, 0);
         w_dma_issue(ws_lds, Wg, wvoff);
         if (nsteps > 1) {
@@ -498,6 +502,58 @@ convgemm_kernel(const ConvGemmArgs p) {
             }
             chunk(std::true_type{}, Xs0 + (size_t)xbs * XBUF, 0u, xtile);
         };
+        // One- and two-tap layers (linears, k = 1 convs, transposed convs) on interior tiles: the same idea with three input
+        // buffers.  Chunk kc + 2's input tile is requested during chunk kc (all of it in a single-tap step, split over the
+        // two steps otherwise), the weight tile of step + 2 during every step; the wait closing a step lets exactly one
+        // step's worth of requests stay in flight (WITER weight + XI input DMAs, whichever two steps they came from).
+        auto run_static = [&](auto taps_tag) {
+            constexpr int TAPS = decltype(taps_tag)::value;
+            constexpr int XI = TAPS == 1 ? XI_1 : XI_2;
+            constexpr int X0N = (XI + TAPS - 1) / TAPS;                            // slices requested in tap 0
+            const unsigned xdst_w = xs_lds + (unsigned)wave * 1024u, wdst_w = ws_lds + (unsigned)wave * 1024u;
+            unsigned wo0 = 0, wo1 = (unsigned)WBUF, wo2 = 2 * (unsigned)WBUF;      // weight buffers of step, step + 1, step + 2
+            unsigned xo0 = 0, xo1 = (unsigned)XBUF, xo2 = 2 * (unsigned)XBUF;      // input buffers of chunk kc, kc + 1, kc + 2
+            // weight tiles of step + 2: single tap -> chunk kc + 2; two taps -> the same tap of chunk kc + 1
+            const TA* wn0 = TAPS == 1 ? Wg + 2 * BK : Wg + BK;
+            const TA* wn1 = wn0 + tap_stride;
+            const TA* xnext = xtile + 2 * BK;                                      // chunk kc + 2, slice 0
+            const int off_step = p.off_step;
+            for (int c = 0; c < nkc; ++c) {
+                const bool more_x = c + 2 < nkc;
+                auto one = [&](auto tap_tag) {
+                    constexpr int tap = decltype(tap_tag)::value;
+                    const bool more_w = c * TAPS + tap + 2 < nsteps;
+                    const TA* wnext = tap == 0 ? wn0 : wn1;
+                    const unsigned wsn = wdst_w + wo2, xsn = xdst_w + xo2;
+                    compute(Xs0 + xo0, Ws0 + wo0, tap * off_step, [&](int kg) {
+                        if (more_w) {
+#pragma unroll
+                            for (int q = 0; q < WITER; ++q)
+                                if ((q < KG ? q : KG - 1) == kg) {
+                                    if (WITER * NW * 64 == WPIECES || (q * NW + wave) * 64 < WPIECES) dma16_so(wnext, wvoff[q], wsn + (unsigned)(q * NW) * 1024u);
+                                    else dma16_so(zero_page, 0u, spare_lds);
+                                }
+                        }
+                        if (more_x && kg == KG - 1) {
+#pragma unroll
+                            for (int i = (tap == 0 ? 0 : X0N); i < (tap == 0 ? X0N : XI); ++i) {
+                                if (i < XI - 1 || last_slice_real) dma16_so(xnext + i * slice_stride, xvoff0, xsn + (unsigned)(i * NW) * 1024u);
+                                else dma16_so(zero_page, 0u, spare_lds);
+                            }
+                        }
+                    });
+                    if (more_w && more_x) wait_vmcnt_c<WITER + XI>();
+                    else if (more_w) wait_vmcnt_c<WITER>();
+                    else wait_vmcnt_c<0>();
+                    block_barrier();
+                    const unsigned t = wo0; wo0 = wo1; wo1 = wo2; wo2 = t;
+                };
+                one(std::integral_constant<int, 0>{});
+                if constexpr (TAPS == 2) one(std::integral_constant<int, 1>{});
+                wn0 += BK; wn1 += BK; xnext += BK;
+                const unsigned t = xo0; xo0 = xo1; xo1 = xo2; xo2 = t;
+            }
+        };
         auto pipeline = [&](auto xps_tag) {
             constexpr int XPS = decltype(xps_tag)::value;
             for (; step < nsteps; ++step) {
@@ -532,6 +588,8 @@ convgemm_kernel(const ConvGemmArgs p) {
             pipeline(tag);
         };
         if (unrolled7) run_unrolled7();
+        else if (static1) run_static(std::integral_constant<int, 1>{});
+        else if (static2) run_static(std::integral_constant<int, 2>{});
         else switch (xps) {
             case 1: run(std::integral_constant<int, 1>{}); break;
             case 2: run(std::integral_constant<int, 2>{}); break;
