@@ -329,6 +329,21 @@ convgemm_kernel(const ConvGemmArgs p) {
         }
     };
 
+    // The fused unit's inner bias and SnakeBeta parameters are fetched HERE and pinned right after the main loop (where
+    // the DMA queue is empty): fetched after the main loop, the compiler's wait for them is a vmcnt(0) that also waits
+    // for the residual rows and the W2 tile requested just before - a round trip to HBM in front of the inner activation.
+    float ia[WN], iib[WN], ibias[WN];                           // the fused unit's inner bias and SnakeBeta
+    auto inner_params = [&]() {                                 // called behind the prologue's requests: the first tiles go first
+        if constexpr (FUSE2) {
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const int n = wn * 32 * WN + j * 32 + (lane & 31);
+                ia[j] = n < p.N ? p.epi_a[n] : 0.f;
+                iib[j] = n < p.N ? p.epi_invb[n] : 0.f;
+                ibias[j] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+            }
+        }
+    };
     if (dma) {
         // ---- LDS-DMA pipeline: weight tiles two steps ahead in three buffers, the next chunk's input tile in slices
         //      spread over this chunk's steps; each step waits with vmcnt(n) for all but the DMAs that may stay in
@@ -350,6 +365,7 @@ convgemm_kernel(const ConvGemmArgs p) {
         const bool static2 = lean2 && p.taps == 2 && p.off_step == 1 && xi_total == XI_2;
         for (int it = 0; it < xi_total; ++it) x_dma_issue(xs_lds, it, 0);
         w_dma_issue(ws_lds, Wg, wvoff);
+        inner_params();
         if (nsteps > 1) {
             w_dma_issue(ws_lds + (unsigned)WBUF, Wg + (p.taps > 1 ? tap_stride : (long long)BK), wvoff);
             if (lean1 || lean2) for (int it = 0; it < xi_total; ++it) x_dma_issue(xs_lds + (unsigned)XBUF, it, 1);
@@ -598,6 +614,7 @@ convgemm_kernel(const ConvGemmArgs p) {
         }
     } else {
         // ---- K tail (narrow test shapes): synchronous register staging, zero-filled past K ----
+        inner_params();
         int kc = 0, tap = 0;
         for (int step = 0; step < nsteps; ++step) {
             if (tap == 0)
@@ -613,6 +630,10 @@ convgemm_kernel(const ConvGemmArgs p) {
 
     const int half = lane >> 5, l31 = lane & 31;
     mark(2);
+    if constexpr (FUSE2) {      // the compiler's wait for the parameters lands here, where the DMA queue is empty
+#pragma unroll
+        for (int j = 0; j < WN; ++j) asm volatile("" : "+v"(ia[j]), "+v"(iib[j]), "+v"(ibias[j]));
+    }
 
     // ---- output addressing (used by the fused unit's residual prefetch and by the epilogue) ----------------------
     TO* __restrict__ Yb = (TO*)p.Y + (long long)b * p.y_batch_stride;
@@ -662,16 +683,6 @@ convgemm_kernel(const ConvGemmArgs p) {
         }
     };
     if constexpr (!FUSE2) column_params();
-    float ia[WN], iib[WN], ibias[WN];                           // the fused unit's inner bias and SnakeBeta
-    if constexpr (FUSE2) {
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int n = wn * 32 * WN + j * 32 + (lane & 31);
-            ia[j] = n < p.N ? p.epi_a[n] : 0.f;
-            iib[j] = n < p.N ? p.epi_invb[n] : 0.f;
-            ibias[j] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
-        }
-    }
     // The fused unit fetches the residual rows (the raw stream, rows of this block only) of each epilogue pass one
     // pass ahead, into registers: the first pass's NOW, so its HBM latency hides under the second contraction, the
     // others' under the pass before them (requested as soon as the registers have been emptied into the slab).
