@@ -174,29 +174,72 @@ __global__ void __launch_bounds__(256) swa_attention_kernel(const T* __restrict_
     const int rs = (nh + 2 * nkv) * d;             // qkv row stride
     const T* base = qkv + (size_t)b * Tn * rs;
 
-    for (int i = tid; i < nk * half; i += 256) {
-        int r = i / half, e = i - r * half;
-        int pos = k_lo + r;
-        const T* kr = base + (size_t)pos * rs + (nh + hk) * d;
-        const T* vr = kr + nkv * d;
-        const int ap = min(pos + shift, max_pos - 1);
-        float c = cos_t[(size_t)ap * half + e], s = sin_t[(size_t)ap * half + e];
-        float x1 = q3_to_f32(kr[e]), x2 = q3_to_f32(kr[e + half]);
-        Ks[r * ds + e] = x1 * c - x2 * s;
-        Ks[r * ds + e + half] = x2 * c + x1 * s;
-        Vs[r * ds + e] = q3_to_f32(vr[e]);
-        Vs[r * ds + e + half] = q3_to_f32(vr[e + half]);
-    }
+    // Staging: one thread takes EPV consecutive dimensions of both rotation halves of a row (16-byte global loads) when
+    // the head size allows, else one dimension pair.  Either way an element is rotated by the same two expressions.
+    constexpr int EPV = 16 / (int)sizeof(T);
     const int nq = q_hi - q0 + 1;
-    for (int i = tid; i < nq * half; i += 256) {
-        int r = i / half, e = i - r * half;
-        int pos = q0 + r;
-        const T* qr = base + (size_t)pos * rs + h * d;
-        const int ap = min(pos + shift, max_pos - 1);
-        float c = cos_t[(size_t)ap * half + e], s = sin_t[(size_t)ap * half + e];
-        float x1 = q3_to_f32(qr[e]), x2 = q3_to_f32(qr[e + half]);
-        Qs[r * d + e] = x1 * c - x2 * s;
-        Qs[r * d + e + half] = x2 * c + x1 * s;
+    auto rot_lo = [](float x1, float x2, float c, float s) { return x1 * c - x2 * s; };
+    auto rot_hi = [](float x1, float x2, float c, float s) { return x2 * c + x1 * s; };
+    if (half % EPV == 0) {
+        const int gpr = half / EPV;                        // groups per half row
+        for (int i = tid; i < nk * gpr; i += 256) {
+            const int r = i / gpr, e = (i - r * gpr) * EPV;
+            const int pos = k_lo + r;
+            const T* kr = base + (size_t)pos * rs + (nh + hk) * d;
+            const T* vr = kr + nkv * d;
+            const int ap = min(pos + shift, max_pos - 1);
+            const uint4 klo = *(const uint4*)(kr + e), khi = *(const uint4*)(kr + e + half);
+            const uint4 vlo = *(const uint4*)(vr + e), vhi = *(const uint4*)(vr + e + half);
+            const float* cr = cos_t + (size_t)ap * half + e;
+            const float* sr = sin_t + (size_t)ap * half + e;
+#pragma unroll
+            for (int u = 0; u < EPV; ++u) {
+                const float x1 = q3_to_f32(((const T*)&klo)[u]), x2 = q3_to_f32(((const T*)&khi)[u]);
+                Ks[r * ds + e + u] = rot_lo(x1, x2, cr[u], sr[u]);
+                Ks[r * ds + e + u + half] = rot_hi(x1, x2, cr[u], sr[u]);
+                Vs[r * ds + e + u] = q3_to_f32(((const T*)&vlo)[u]);
+                Vs[r * ds + e + u + half] = q3_to_f32(((const T*)&vhi)[u]);
+            }
+        }
+        for (int i = tid; i < nq * gpr; i += 256) {
+            const int r = i / gpr, e = (i - r * gpr) * EPV;
+            const int pos = q0 + r;
+            const T* qr = base + (size_t)pos * rs + h * d;
+            const int ap = min(pos + shift, max_pos - 1);
+            const uint4 qlo = *(const uint4*)(qr + e), qhi = *(const uint4*)(qr + e + half);
+            const float* cr = cos_t + (size_t)ap * half + e;
+            const float* sr = sin_t + (size_t)ap * half + e;
+#pragma unroll
+            for (int u = 0; u < EPV; ++u) {
+                const float x1 = q3_to_f32(((const T*)&qlo)[u]), x2 = q3_to_f32(((const T*)&qhi)[u]);
+                Qs[r * d + e + u] = rot_lo(x1, x2, cr[u], sr[u]);
+                Qs[r * d + e + u + half] = rot_hi(x1, x2, cr[u], sr[u]);
+            }
+        }
+    } else {
+        for (int i = tid; i < nk * half; i += 256) {
+            int r = i / half, e = i - r * half;
+            int pos = k_lo + r;
+            const T* kr = base + (size_t)pos * rs + (nh + hk) * d;
+            const T* vr = kr + nkv * d;
+            const int ap = min(pos + shift, max_pos - 1);
+            float c = cos_t[(size_t)ap * half + e], s = sin_t[(size_t)ap * half + e];
+            float x1 = q3_to_f32(kr[e]), x2 = q3_to_f32(kr[e + half]);
+            Ks[r * ds + e] = rot_lo(x1, x2, c, s);
+            Ks[r * ds + e + half] = rot_hi(x1, x2, c, s);
+            Vs[r * ds + e] = q3_to_f32(vr[e]);
+            Vs[r * ds + e + half] = q3_to_f32(vr[e + half]);
+        }
+        for (int i = tid; i < nq * half; i += 256) {
+            int r = i / half, e = i - r * half;
+            int pos = q0 + r;
+            const T* qr = base + (size_t)pos * rs + h * d;
+            const int ap = min(pos + shift, max_pos - 1);
+            float c = cos_t[(size_t)ap * half + e], s = sin_t[(size_t)ap * half + e];
+            float x1 = q3_to_f32(qr[e]), x2 = q3_to_f32(qr[e + half]);
+            Qs[r * d + e] = rot_lo(x1, x2, c, s);
+            Qs[r * d + e + half] = rot_hi(x1, x2, c, s);
+        }
     }
     __syncthreads();
 
