@@ -239,7 +239,14 @@ class Decoder:
         out = torch.empty(total, dtype=torch.float32, device=self.device)
         if not items:
             return out, starts, lengths
-        dev_items = [c.to(self.device) for c in items]
+        if len(items) > 1 and all(c.device.type == "cpu" for c in items):      # one copy to the device, then views
+            flat_codes = torch.cat(items, dim=1).to(self.device)
+            dev_items, o = [], 0
+            for c in items:
+                dev_items.append(flat_codes[:, o:o + int(c.shape[1])])
+                o += int(c.shape[1])
+        else:
+            dev_items = [c.to(self.device) for c in items]
         buckets: Dict[int, List[int]] = {}
         for j, (_i, s, e, _ctx, _off) in enumerate(jobs):
             buckets.setdefault(-(-(e - s) // pad_to) * pad_to, []).append(j)
@@ -267,8 +274,39 @@ class Decoder:
         length share a launch sequence, and each piece keeps only its own prefix of the output (a frame never
         influences samples that precede it by more than the fixed 555-sample lookahead)."""
         out, starts, lengths = self.decode_device(encoded, chunk_size, left_context_size, pad_to)
-        host = out.cpu().numpy()
-        return [host[s:s + n].copy() for s, n in zip(starts, lengths)], self.cfg.sample_rate
+        host = self._to_host(out)
+        return [host[s:s + n] for s, n in zip(starts, lengths)], self.cfg.sample_rate
+
+    def _to_host(self, flat: torch.Tensor) -> np.ndarray:
+        """Device samples -> one numpy array, through two pinned staging buffers: the copy of piece k + 1 from the GPU runs
+        while piece k moves from its staging buffer into the result (a pageable copy of the whole tensor is several
+        times slower, and pinning a result-sized buffer per call costs more than it saves)."""
+        n = int(flat.numel())
+        res = np.empty(n, dtype=np.float32)
+        if n == 0:
+            return res
+        piece = 32 << 20                                    # elements (128 MiB) per staging buffer
+        if n <= (1 << 20):                                  # small results: not worth the staging
+            res[:] = flat.cpu().numpy()
+            return res
+        if self.__dict__.get("_stage") is None:
+            self._stage = [torch.empty(piece, dtype=torch.float32, pin_memory=True) for _ in range(2)]
+            self._stage_ev = [torch.cuda.Event() for _ in range(2)]
+        stream = torch.cuda.current_stream(self.device)
+        bounds = [(a, min(a + piece, n)) for a in range(0, n, piece)]
+        with torch.cuda.device(self.device):
+            for k, (a, b) in enumerate(bounds[:2]):
+                self._stage[k][: b - a].copy_(flat[a:b], non_blocking=True)
+                self._stage_ev[k].record(stream)
+            for k, (a, b) in enumerate(bounds):
+                j = k & 1
+                self._stage_ev[j].synchronize()
+                res[a:b] = self._stage[j][: b - a].numpy()
+                if k + 2 < len(bounds):
+                    a2, b2 = bounds[k + 2]
+                    self._stage[j][: b2 - a2].copy_(flat[a2:b2], non_blocking=True)
+                    self._stage_ev[j].record(stream)
+        return res
 
     # ------------------------------------------------------------------------------------------------
     def profile(self, on: bool, detail: bool = False) -> None:
