@@ -181,6 +181,13 @@ int q3c_convnext_block(const float* x_dev, int32_t batch, int32_t length, int32_
 int q3c_transformer(q3c_ctx* ctx, const float* x_dev, int32_t batch, int32_t frames, float* y_dev, void* workspace_dev,
                     size_t workspace_bytes, void* hip_stream);
 
+/* -- output format -------------------------------------------------------------------------------------------
+ * The reference packs every waveform as a PCM_16 WAV file before it leaves the server (server.py:108-113, 117-121:
+ * soundfile.write(buffer, wav, sample_rate, format="WAV"), whose default subtype is PCM_16).  This is that conversion on
+ * the device - libsndfile's float -> short rule, lrintf(x * 32767) with round-half-to-even, saturated outside [-1, 1] -
+ * so that half the bytes cross PCIe.  Asynchronous on the stream; wav and pcm are device pointers. */
+int q3c_wav_to_pcm16(const float* wav_dev, int64_t samples, int16_t* pcm_dev, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,7 +22,7 @@ EXPORTS = ["q3c_create", "q3c_destroy", "q3c_last_error", "q3c_version", "q3c_lo
            "q3c_set_tap", "q3c_causal_conv1d", "q3c_causal_tconv1d", "q3c_snake_beta", "q3c_profile_enable",
            "q3c_profile_read", "q3c_stream_pool_create", "q3c_stream_pool_destroy", "q3c_stream_state_bytes",
            "q3c_stream_reset", "q3c_stream_workspace_bytes", "q3c_stream_push", "q3c_residual_unit", "q3c_convnext_block",
-           "q3c_transformer"]
+           "q3c_transformer", "q3c_wav_to_pcm16"]
 
 
 class Q3cProfileEntry(C.Structure):
@@ -87,6 +87,7 @@ def load() -> C.CDLL:
     lib.q3c_residual_unit.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp, i32, vp]
     lib.q3c_convnext_block.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp, i32, vp]
     lib.q3c_transformer.argtypes = [vp, vp, i32, i32, vp, vp, C.c_size_t, vp]
+    lib.q3c_wav_to_pcm16.argtypes = [vp, C.c_int64, vp, vp]
     lib.q3c_profile_enable.argtypes = [vp, i32]
     lib.q3c_profile_read.argtypes = [vp, C.POINTER(Q3cProfileEntry), i32, C.POINTER(i32)]
     lib.q3c_stream_pool_create.argtypes = [vp, i32, C.POINTER(vp)]

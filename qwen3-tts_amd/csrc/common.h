@@ -90,6 +90,7 @@ hipError_t q3_launch_stream_reset(const int* slots, int count, int capacity, voi
                                   int* err_flag, hipStream_t s);
 hipError_t q3_launch_cast_to_f32(const void* x, float* y, long long n, int dtype, hipStream_t s);
 hipError_t q3_launch_cast_from_f32(const float* x, void* y, long long n, int dtype, hipStream_t s);
+hipError_t q3_launch_pcm16(const float* x, short* y, long long n, hipStream_t s);
 hipError_t q3_launch_snake(const void* x, void* y, const float* a, const float* invb, long long rows, int C, int dtype, hipStream_t s);
 
 // ---- device helpers -------------------------------------------------------------------------------

@@ -1320,4 +1320,11 @@ int q3c_transformer(q3c_ctx* c, const float* x, int32_t B, int32_t T, float* y, 
     return 0;
 }
 
+// fp32 samples -> 16-bit PCM on the device (asynchronous on the stream)
+int q3c_wav_to_pcm16(const float* wav, int64_t samples, int16_t* pcm, void* stream) {
+    if ((!wav || !pcm) && samples > 0) return Q3C_ERR_INVALID_ARGUMENT;
+    if (samples < 0) return Q3C_ERR_INVALID_ARGUMENT;
+    return q3_launch_pcm16(wav, (short*)pcm, (long long)samples, (hipStream_t)stream) == hipSuccess ? 0 : Q3C_ERR_HIP;
+}
+
 }  // extern "C"

@@ -510,6 +510,24 @@ hipError_t q3_launch_cast_from_f32(const float* x, void* y, long long n, int dty
     return hipGetLastError();
 }
 
+// float samples -> 16-bit PCM the way libsndfile writes a float array to a PCM_16 file: lrintf(x * 32767), round half to
+// even (the reference's sf.write(buffer, wav, sr, format="WAV"), server.py:108-113); saturated outside [-1, 1]
+__global__ void __launch_bounds__(256) pcm16_kernel(const float* __restrict__ x, short* __restrict__ y, long long n) {
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long stride = (long long)gridDim.x * 256;
+    for (; i < n; i += stride) {
+        const float v = fminf(32767.0f, fmaxf(-32768.0f, __fmul_rn(x[i], 32767.0f)));
+        y[i] = (short)__float2int_rn(v);
+    }
+}
+
+hipError_t q3_launch_pcm16(const float* x, short* y, long long n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    unsigned g = (unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
+    hipLaunchKernelGGL(pcm16_kernel, dim3(g), dim3(256), 0, s, x, y, n);
+    return hipGetLastError();
+}
+
 hipError_t q3_launch_snake(const void* x, void* y, const float* a, const float* invb, long long rows, int C, int dtype, hipStream_t s) {
     long long n = rows * C;
     if (n == 0) return hipSuccess;

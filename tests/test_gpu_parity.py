@@ -294,3 +294,25 @@ def test_batcher_equals_direct_decode():
         for x, y in zip(a, b):           # another batch mix pads to other lengths: fp32 reductions regroup, nothing more
             assert x.shape == y.shape and max_abs(x, y) <= 1e-5
 
+
+def test_pcm16_bit_exact_vs_oracle():
+    """Device float -> PCM_16 against the oracle: random samples, every tie of the form (k + 0.5) / 32767, the ends of
+    the range; and decode_pcm16 against the oracle applied to decode()'s samples."""
+    import pcm16_oracle as po
+    from qwen3_tts_amd import audio
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(1 << 20, generator=g) * 2 - 1
+    ties = (torch.arange(-32768, 32768, dtype=torch.float32) + 0.5) / 32767.0
+    edge = torch.tensor([0.0, -0.0, 1.0, -1.0, 1e-9, -1e-9, 2.0, -2.0, 0.99999, -0.99999])
+    allx = torch.cat([x, ties, edge])
+    got = audio.to_pcm16(allx.cuda()).cpu().numpy()
+    assert got.dtype == np.int16 and np.array_equal(got, po.float_to_pcm16(allx.numpy()))
+    cfg = q3.tiny_config()
+    dec = _decoder(cfg, q3.synthetic_weights(cfg, seed=2), "f32")
+    items = [q3.random_codes(cfg, 1, t, seed=t)[0] for t in (3, 17, 40)]
+    wavs, sr = dec.decode(items)
+    pcms, sr2 = audio.decode_pcm16(dec, items)
+    assert sr == sr2 == 24000
+    for w, p_ in zip(wavs, pcms):
+        assert np.array_equal(p_, po.float_to_pcm16(w))
+

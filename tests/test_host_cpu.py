@@ -340,3 +340,15 @@ def test_batcher_errors_stay_with_their_request():
         assert len(f3.result()[0]) == 2
     with pytest.raises(RuntimeError):
         bat.submit(good)
+
+
+def test_wav_container_and_base64_match_the_oracle():
+    import base64
+    import pcm16_oracle as po
+    from qwen3_tts_amd import audio
+    pcm = po.float_to_pcm16(np.cos(np.arange(777, dtype=np.float32) * 0.02))
+    assert audio.wav_file_bytes(pcm, 24000) == po.wav_file_bytes(pcm, 24000)
+    assert base64.b64decode(audio.audio_to_base64(pcm, 24000)) == po.wav_file_bytes(pcm, 24000)
+    with pytest.raises(ValueError):
+        audio.to_pcm16(torch.zeros(4))                                 # no host-side conversion path
+

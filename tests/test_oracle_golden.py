@@ -120,3 +120,20 @@ def test_decode_wrapper_returns_numpy_list(golden):
     wavs, sr = oracle.decode(cfg, w, items)
     assert sr == 24000 and [x.shape for x in wavs] == [(2 * 1920 - 555,), (5 * 1920 - 555,)]
     assert all(x.dtype == np.float32 for x in wavs)
+
+
+def test_pcm16_oracle_known_answers_and_wav_container():
+    """Float -> PCM_16 rule (lrintf(x * 32767), ties to even) on hand-checked values, and the WAV container against
+    scipy's writer (the conversion itself is unpinned: soundfile is not in the container)."""
+    import io
+    import pcm16_oracle as po
+    from scipy.io import wavfile
+    x = np.array([0.0, -0.0, 1.0, -1.0, 0.5, 0.5 / 32767, 1.5 / 32767, 2.5 / 32767, -0.5 / 32767, -1.5 / 32767, 1e-9, 2.0, -2.0],
+                 dtype=np.float32)
+    want = np.array([0, 0, 32767, -32767, 16384, 0, 2, 2, 0, -2, 0, 32767, -32768], dtype=np.int16)
+    assert np.array_equal(po.float_to_pcm16(x), want)                 # 0.5 * 32767 = 16383.5 -> 16384 (even)
+    pcm = po.float_to_pcm16(np.sin(np.arange(1000, dtype=np.float32) * 0.01))
+    buf = io.BytesIO()
+    wavfile.write(buf, 24000, pcm)
+    assert po.wav_file_bytes(pcm, 24000) == buf.getvalue()
+
