@@ -316,3 +316,42 @@ def test_pcm16_bit_exact_vs_oracle():
     for w, p_ in zip(wavs, pcms):
         assert np.array_equal(p_, po.float_to_pcm16(w))
 
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_operators_at_production_tile_shapes(precision):
+    """Layers of the flagship decoder's widths on enough rows (>= 8192) to take the tile shapes and main loops the
+    headline benchmark runs (two-block 256 x 128 tiles, fused 256 x 96 / 128 x 192 units, the unrolled seven-tap loop,
+    the static one- and two-tap loops, the branch-free epilogue), with rows that do not fill the last tile; against
+    the oracle's operators on the CPU."""
+    from qwen3_tts_amd import decoder as D
+    g = torch.Generator().manual_seed(11)
+    rnd = lambda *shape, s=1.0: torch.randn(*shape, generator=g) * s
+    B, L = 2, 4500                                            # 9000 rows: interior tiles, a sequence start and a partial tail per item
+    worst = {}
+
+    def check(tag, got, want):
+        want = want.permute(0, 2, 1).numpy()
+        got = got.cpu().numpy()
+        assert got.shape == want.shape, (tag, got.shape, want.shape)
+        err, top = max_abs(want, got), float(np.abs(want).max())
+        worst[tag] = err / top
+        bound = (2e-5 if precision == "f32" else BF16_CHAIN_REL) * max(top, 1.0)
+        assert err <= bound, f"{tag} ({precision}): max|err| {err:.3e} > {bound:.3e} (max|y| {top:.2f})"
+
+    for C, d in ((96, 9), (192, 3), (384, 1)):
+        w = {"ru.act1.alpha": rnd(C, s=0.3), "ru.act1.beta": rnd(C, s=0.3), "ru.conv1.conv.weight": rnd(C, C, 7, s=(7 * C) ** -0.5),
+             "ru.conv1.conv.bias": rnd(C, s=0.1), "ru.act2.alpha": rnd(C, s=0.3), "ru.act2.beta": rnd(C, s=0.3),
+             "ru.conv2.conv.weight": rnd(C, C, 1, s=C ** -0.5), "ru.conv2.conv.bias": rnd(C, s=0.1)}
+        x = rnd(B, C, L)
+        check(f"resunit{C}", D.residual_unit(x.permute(0, 2, 1).contiguous().cuda(), w, "ru.", d, precision=precision),
+              oracle.residual_unit(x, w, "ru.", d))
+    for cin, cout, s_ in ((384, 192, 4), (192, 96, 3)):
+        w, b = rnd(cin, cout, 2 * s_, s=(2 * cin) ** -0.5), rnd(cout, s=0.1)
+        x = rnd(B, cin, L)
+        check(f"tconv{cin}", D.causal_trans_conv1d(x.permute(0, 2, 1).contiguous().cuda(), w, b, s_, precision),
+              oracle.causal_trans_conv1d(x, w, b, s_))
+    w, b = rnd(1024, 1024, 1, s=1024 ** -0.5), rnd(1024, s=0.1)
+    x = rnd(B, 1024, L)
+    check("linear1024", D.causal_conv1d(x.permute(0, 2, 1).contiguous().cuda(), w, b, 1, precision), oracle.causal_conv1d(x, w, b, 1, 1))
+    print(f"production shapes {precision}: max|err| / max|y| " + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
+
