@@ -127,8 +127,10 @@ __device__ __forceinline__ float q3_sin_f32(float x) {
 template <typename T> __device__ __forceinline__ float q3_sin(float x);
 template <> __device__ __forceinline__ float q3_sin<float>(float x) { return q3_sin_f32(x); }
 // bf16 path: the hardware sine takes its argument in REVOLUTIONS; the host folds 1/(2 pi) into the per-channel
-// frequency it uploads for bf16 contexts, so q3_snake<bf16> is mul, v_sin, mul, fma.
-template <> __device__ __forceinline__ float q3_sin<bf16>(float x) { return __builtin_amdgcn_sinf(x); }
+// frequency it uploads for bf16 contexts, so q3_snake<bf16> is mul, v_fract, v_sin, mul, fma.  v_sin_f32 is only
+// specified for |revolutions| <= 256 (beyond that it returns 0); sine has period one revolution, so the fractional
+// part (v_fract_f32: x - floor(x), exact) is taken first and trained alpha * x of any size keeps its sin^2 term.
+template <> __device__ __forceinline__ float q3_sin<bf16>(float x) { return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(x)); }
 
 template <typename T> __device__ __forceinline__ float q3_snake(float x, float a, float invb) {
     float s = q3_sin<T>(x * a);

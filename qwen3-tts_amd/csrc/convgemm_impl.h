@@ -79,7 +79,9 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_c() {
 // One LDS-DMA instruction: 16 bytes per lane from global memory to LDS at lds_addr + lane * 16 (lds_addr wave-uniform).
 // Issued through inline asm on purpose: the compiler then neither counts it nor guards later ds_reads with vmcnt(0), so
 // tiles can stay in flight across steps; completion is tracked by wait_vmcnt below.  M0 (the LDS base of an LDS-DMA) is
-// written in the same statement; nothing else in these kernels uses M0.
+// written in the same statement.  M0 is a reserved register of the AMDGPU backend: it is never allocated to a value, and the
+// compiler's own uses of it write it immediately before the instruction that reads it, so nothing can be live in M0 across
+// one of these statements (naming it in the clobber list is rejected as "reserved register" for that reason).
 //   dma16    : every lane supplies a full 64-bit address
 //   dma16_so : wave-uniform 64-bit base (SGPR pair) + unsigned 32-bit per-lane byte offset
 __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_addr) {
@@ -101,13 +103,14 @@ __device__ __forceinline__ void block_barrier() {
 
 // Waves per SIMD the register allocation must leave room for: the 8-wave 64-byte-row shape runs two blocks per CU (four
 // waves per SIMD, 128 registers each); every other shape two waves per SIMD.
-template <int NW, int WM, int WN, int BKB, bool FUSE2> constexpr int waves_per_simd() {
-    return (NW == 8 && !FUSE2 && BKB == 64 && WM * WN <= 4) ? 4 : 2;
+template <typename TA, typename TO, int NW, int WM, int WN, int BKB, bool FUSE2> constexpr int waves_per_simd() {
+    // fp32 operands or outputs (the parity path, taps) need more than 128 registers in that shape: one block per CU there
+    return (sizeof(TA) == 2 && sizeof(TO) == 2 && NW == 8 && !FUSE2 && BKB == 64 && WM * WN <= 4) ? 4 : 2;
 }
 
 template <typename TA, typename TO, int WAVES_M, int WAVES_N, int WM, int WN, int BKB, bool FUSE2, bool SEG>
 __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N)
-__attribute__((amdgpu_waves_per_eu(waves_per_simd<WAVES_M * WAVES_N, WM, WN, BKB, FUSE2>())))
+__attribute__((amdgpu_waves_per_eu(waves_per_simd<TA, TO, WAVES_M * WAVES_N, WM, WN, BKB, FUSE2>())))
 convgemm_kernel(const ConvGemmArgs p) {
     constexpr int NW = WAVES_M * WAVES_N;            // waves per block
     constexpr int NTHR = 64 * NW;
@@ -502,7 +505,7 @@ convgemm_kernel(const ConvGemmArgs p) {
             auto chunk = [&](auto last_tag, const unsigned char* xs, unsigned xsn, const TA* xnext) {
                 // With 128 registers per wave the seven taps' fragment addresses must not be kept across chunks (they
                 // spill, and a reload's wait drains the DMA queue): hide the tap offset's loop invariance from the compiler.
-                if constexpr (waves_per_simd<NW, WM, WN, BKB, FUSE2>() == 4) asm volatile("" : "+s"(off_step));
+                if constexpr (waves_per_simd<TA, TO, NW, WM, WN, BKB, FUSE2>() == 4) asm volatile("" : "+s"(off_step));
                 one(std::integral_constant<int, 0>{}, last_tag, xs, xsn, xnext);
                 one(std::integral_constant<int, 1>{}, last_tag, xs, xsn, xnext);
                 one(std::integral_constant<int, 2>{}, last_tag, xs, xsn, xnext);

@@ -421,6 +421,14 @@ int validate_config(q3c_ctx* c) {
         return bad("stage counts out of range");
     if (k.codebook_size < 1 || k.num_quantizers < 1 || k.num_semantic_quantizers < 1 || k.num_semantic_quantizers > k.num_quantizers)
         return bad("codebook sizes out of range");
+    if (k.num_attention_heads < 1 || k.num_key_value_heads < 1 || k.head_dim < 2 || k.hidden_size < 1 || k.latent_dim < 1 ||
+        k.intermediate_size < 1 || k.num_hidden_layers < 0 || k.decoder_dim < 1)
+        return bad("sizes must be positive");
+    if (k.frontend == Q3C_FRONTEND_SPLIT_RVQ && (k.codebook_dim < 1 || k.rvq_out_dim < 1 || k.pre_conv_kernel < 1))
+        return bad("front-end sizes must be positive");
+    for (int i = 0; i < k.num_upsampling_ratios; ++i) if (k.upsampling_ratios[i] < 1) return bad("upsampling_ratios must be >= 1");
+    for (int i = 0; i < k.num_upsample_rates; ++i) if (k.upsample_rates[i] < 1) return bad("upsample_rates must be >= 1");
+    for (int i = 0; i < k.num_dilations; ++i) if (k.dilations[i] < 1) return bad("dilations must be >= 1");
     if (k.num_attention_heads % k.num_key_value_heads || (k.head_dim & 1)) return bad("attention head layout");
     if (k.frontend == Q3C_FRONTEND_MEAN_EMBEDDING && (k.io_proj || k.latent_dim != k.hidden_size))
         return bad("mean_embedding front end needs io_proj = 0 and latent_dim == hidden_size");
@@ -1069,8 +1077,6 @@ int q3c_stream_pool_create(q3c_ctx* c, int32_t capacity, q3c_stream_pool** out) 
     if (!c || !out) return Q3C_ERR_INVALID_ARGUMENT;
     if (!c->finalized) return fail(c, Q3C_ERR_STATE, "q3c_finalize has not run");
     if (capacity < 1) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "stream pool capacity must be >= 1");
-    for (int i = 0; i < c->cfg.num_dilations; ++i)
-        if (c->cfg.dilations[i] < 1) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "dilations must be >= 1");
     q3c_stream_pool* P = new q3c_stream_pool();
     P->c = c; P->capacity = capacity;
     long long st = 0;
@@ -1172,13 +1178,14 @@ int q3c_causal_conv1d(const float* x, int32_t B, int32_t L, int32_t cin, int32_t
 
 int q3c_causal_tconv1d(const float* x, int32_t B, int32_t L, int32_t cin, int32_t cout, int32_t k, int32_t stride, const float* w,
                        const float* bias, float* y, int32_t precision, void* stream) {
-    if (!x || !w || !y || B < 1 || L < 1 || cin % 8 || cout < 1 || stride < 1) return Q3C_ERR_INVALID_ARGUMENT;
+    if (!x || !w || !y || B < 1 || L < 1 || cin < 8 || cin % 8 || cout < 1 || stride < 1 || k < 1) return Q3C_ERR_INVALID_ARGUMENT;
     q3c_ctx tmp;
     const int dt = precision == Q3C_PRECISION_BF16 ? Q3_BF16 : Q3_F32;
     GemmW g;
     int rc = pack_tconv_host(&tmp, w, bias, cin, cout, k, stride, dt, &g);
     const int M = (k == stride) ? L : L - 1;
-    if (!rc && M >= 1) rc = op_run(g, &tmp, x, B, L, cin, y, M, stride * cout, precision, (hipStream_t)stream);
+    if (!rc && M < 1) rc = fail(&tmp, Q3C_ERR_INVALID_ARGUMENT, "the two-sided trim leaves no output rows (length 1 with kernel == 2*stride)");
+    if (!rc) rc = op_run(g, &tmp, x, B, L, cin, y, M, stride * cout, precision, (hipStream_t)stream);
     if (rc) fprintf(stderr, "q3c_causal_tconv1d: %s\n", tmp.err.c_str());
     for (void* p : tmp.allocs) (void)hipFree(p);
     return rc;

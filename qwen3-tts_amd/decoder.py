@@ -311,28 +311,6 @@ class Decoder:
                     self._stage[j][: b2 - a2].copy_(bytes_dev[a2:b2], non_blocking=True)
                     self._stage_ev[j].record(stream)
         return res
-        piece = 32 << 20                                    # elements (128 MiB) per staging buffer
-        if n <= (1 << 20):                                  # small results: not worth the staging
-            res[:] = flat.cpu().numpy()
-            return res
-        if self.__dict__.get("_stage") is None:
-            self._stage = [torch.empty(piece, dtype=torch.float32, pin_memory=True) for _ in range(2)]
-            self._stage_ev = [torch.cuda.Event() for _ in range(2)]
-        stream = torch.cuda.current_stream(self.device)
-        bounds = [(a, min(a + piece, n)) for a in range(0, n, piece)]
-        with torch.cuda.device(self.device):
-            for k, (a, b) in enumerate(bounds[:2]):
-                self._stage[k][: b - a].copy_(flat[a:b], non_blocking=True)
-                self._stage_ev[k].record(stream)
-            for k, (a, b) in enumerate(bounds):
-                j = k & 1
-                self._stage_ev[j].synchronize()
-                res[a:b] = self._stage[j][: b - a].numpy()
-                if k + 2 < len(bounds):
-                    a2, b2 = bounds[k + 2]
-                    self._stage[j][: b2 - a2].copy_(flat[a2:b2], non_blocking=True)
-                    self._stage_ev[j].record(stream)
-        return res
 
     # ------------------------------------------------------------------------------------------------
     def profile(self, on: bool, detail: bool = False) -> None:

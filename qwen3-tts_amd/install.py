@@ -78,50 +78,88 @@ def _get(cfg_obj: Any, name: str, default: Any = None) -> Any:
     return getattr(cfg_obj, name, default)
 
 
+# Sizes a tensor shape determines.  They are NEVER read from the model's config object: upstream configs reuse some of
+# these names with another meaning (its `codebook_dim` is the RVQ in/out width, twice this package's code-book row width).
+_SHAPE_FIELDS = ("frontend", "codebook_size", "codebook_dim", "rvq_out_dim", "num_quantizers", "num_semantic_quantizers",
+                 "pre_conv_kernel", "latent_dim", "hidden_size", "io_proj", "num_hidden_layers", "intermediate_size", "decoder_dim")
+
+
 def config_from_weights(cfg_obj: Any, w: Dict[str, torch.Tensor]) -> DecoderConfig:
-    """Architecture from the module's config object (or dict), with every size that a tensor shape determines taken
-    from the shape; a disagreement between the two is an error."""
+    """Architecture of the decoder whose tensors are `w`.  Every size a tensor shape determines comes from the shape
+    alone; the config object (or dict) only supplies what no shape shows (head count, window, rates, epsilons, rope
+    theta), and what it says there is cross-checked against the shapes where one exists."""
     base = DecoderConfig()
     fields: Dict[str, Any] = {}
     for f in base.to_dict():
+        if f in _SHAPE_FIELDS:
+            continue
         v = _get(cfg_obj, f)
         if v is not None:
             fields[f] = tuple(v) if isinstance(v, (list, tuple)) else v
 
-    def agree(name: str, value: Any) -> None:
+    def put(name: str, value: Any) -> None:
         if name in fields and fields[name] != value:
-            raise ValueError(f"decoder config says {name} = {fields[name]!r} but the weights imply {value!r}")
+            raise ValueError(f"the weights imply {name} = {fields[name]!r} in one place and {value!r} in another")
         fields[name] = value
 
     if "code_embedding.weight" in w:
-        agree("frontend", FRONTEND_MEAN_EMBEDDING)
-        agree("hidden_size", int(w["code_embedding.weight"].shape[1]))
+        put("frontend", FRONTEND_MEAN_EMBEDDING)
+        rows, width = w["code_embedding.weight"].shape
+        put("hidden_size", int(width))
+        # one table of codebook_size * num_quantizers rows: the shape fixes only the product, the config splits it
+        for f in ("codebook_size", "num_quantizers"):
+            v = _get(cfg_obj, f)
+            if v is not None:
+                fields[f] = int(v)
+        bins, nq = fields.get("codebook_size", base.codebook_size), fields.get("num_quantizers", base.num_quantizers)
+        if bins * nq != int(rows):
+            raise ValueError(f"code_embedding has {int(rows)} rows but codebook_size * num_quantizers = {bins} * {nq}")
+        v = _get(cfg_obj, "num_semantic_quantizers")
+        if v is not None:
+            fields["num_semantic_quantizers"] = int(v)
     elif "quantizer.semantic.layers.0.embed_sum" in w:
-        agree("frontend", FRONTEND_SPLIT_RVQ)
+        put("frontend", FRONTEND_SPLIT_RVQ)
         n_sem = sum(1 for k in w if k.startswith("quantizer.semantic.layers.") and k.endswith(".embed_sum"))
         n_ac = sum(1 for k in w if k.startswith("quantizer.acoustic.layers.") and k.endswith(".embed_sum"))
         bins, dim = w["quantizer.semantic.layers.0.embed_sum"].shape
-        agree("num_semantic_quantizers", n_sem)
-        agree("num_quantizers", n_sem + n_ac)
-        agree("codebook_size", int(bins))
-        agree("codebook_dim", int(dim))
-        agree("rvq_out_dim", int(w["quantizer.semantic.output_proj.weight"].shape[0]))
+        put("num_semantic_quantizers", n_sem)
+        put("num_quantizers", n_sem + n_ac)
+        put("codebook_size", int(bins))
+        put("codebook_dim", int(dim))
+        put("rvq_out_dim", int(w["quantizer.semantic.output_proj.weight"].shape[0]))
         lt, _cin, k = w["pre_conv.conv.weight"].shape
-        agree("latent_dim", int(lt))
-        agree("pre_conv_kernel", int(k))
+        put("latent_dim", int(lt))
+        put("pre_conv_kernel", int(k))
     else:
-        raise KeyError("state dict has neither 'code_embedding.weight' nor 'quantizer.semantic.layers.0.embed_sum'")
-    agree("io_proj", "pre_transformer.input_proj.weight" in w)
+        raise KeyError("state dict has neither 'code_embedding.weight' nor 'quantizer.semantic.layers.0.embed_sum'; "
+                       "pass rename= to install_decoder if the checkpoint uses other key names")
+    put("io_proj", "pre_transformer.input_proj.weight" in w)
     n_layers = 0
     while f"pre_transformer.layers.{n_layers}.input_layernorm.weight" in w:
         n_layers += 1
-    agree("num_hidden_layers", n_layers)
+    put("num_hidden_layers", n_layers)
     if n_layers:
-        agree("hidden_size", int(w["pre_transformer.layers.0.input_layernorm.weight"].shape[0]))
-        agree("intermediate_size", int(w["pre_transformer.layers.0.mlp.gate_proj.weight"].shape[0]))
+        put("hidden_size", int(w["pre_transformer.layers.0.input_layernorm.weight"].shape[0]))
+        put("intermediate_size", int(w["pre_transformer.layers.0.mlp.gate_proj.weight"].shape[0]))
+        qd = int(w["pre_transformer.layers.0.self_attn.q_proj.weight"].shape[0])
+        kvd = int(w["pre_transformer.layers.0.self_attn.k_proj.weight"].shape[0])
+        heads = int(fields.get("num_attention_heads", base.num_attention_heads))
+        if qd % heads:
+            raise ValueError(f"q_proj has {qd} rows, not a multiple of num_attention_heads = {heads}")
+        hd = qd // heads
+        if "head_dim" in fields and int(fields["head_dim"]) != hd:
+            raise ValueError(f"decoder config says head_dim = {fields['head_dim']} but q_proj implies {hd}")
+        fields["num_attention_heads"], fields["head_dim"] = heads, hd
+        if kvd % hd:
+            raise ValueError(f"k_proj has {kvd} rows, not a multiple of head_dim = {hd}")
+        if "num_key_value_heads" in fields and int(fields["num_key_value_heads"]) != kvd // hd:
+            raise ValueError(f"decoder config says num_key_value_heads = {fields['num_key_value_heads']} but k_proj implies {kvd // hd}")
+        fields["num_key_value_heads"] = kvd // hd
+    elif "hidden_size" not in fields:
+        put("hidden_size", int(w[_ANCHOR].shape[1]))
     dd, lt, _k = w[_ANCHOR].shape
-    agree("decoder_dim", int(dd))
-    agree("latent_dim", int(lt))
+    put("decoder_dim", int(dd))
+    put("latent_dim", int(lt))
     cfg = DecoderConfig.from_dict(fields)
     missing = [n for n, shape, _kind, _fan in param_specs(cfg) if n not in w or tuple(w[n].shape) != tuple(shape)]
     if missing:
@@ -129,13 +167,32 @@ def config_from_weights(cfg_obj: Any, w: Dict[str, torch.Tensor]) -> DecoderConf
     return cfg
 
 
+def rename_weights(w: Dict[str, torch.Tensor], rename: Optional[Dict[str, str]]) -> Dict[str, torch.Tensor]:
+    """Apply a key-rename map: each (old, new) pair replaces the substring `old` by `new` in every key that contains
+    it.  Unknown key names are never guessed; a checkpoint that names its tensors differently is loaded by passing the
+    map explicitly."""
+    if not rename:
+        return w
+    out: Dict[str, torch.Tensor] = {}
+    for k, v in w.items():
+        for old, new in rename.items():
+            if old in k:
+                k = k.replace(old, new)
+        if k in out:
+            raise ValueError(f"rename map sends two tensors to '{k}'")
+        out[k] = v
+    return out
+
+
 def install_decoder(model: Any, precision: str = "bf16", device: Optional[Any] = None,
-                    decoder_factory: Optional[Callable[..., Any]] = None, **decoder_kwargs: Any) -> Any:
+                    decoder_factory: Optional[Callable[..., Any]] = None, rename: Optional[Dict[str, str]] = None,
+                    **decoder_kwargs: Any) -> Any:
     """Find the model's speech tokenizer, build a `Decoder` from its weights on `device` (default: where those weights
     live) and replace the tokenizer's `decode` with it.  The previous bound method stays reachable as
-    `tokenizer.reference_decode`.  Returns the new decoder."""
+    `tokenizer.reference_decode`.  `rename` maps key substrings of the checkpoint to the names this package uses
+    (see rename_weights).  Returns the new decoder."""
     tok, dec_mod = find_speech_tokenizer(model)
-    w = decoder_weights(dec_mod)
+    w = rename_weights(decoder_weights(dec_mod), rename)
     cfg = config_from_weights(getattr(dec_mod, "config", None) or getattr(tok, "decoder_config", None) or {}, w)
     if device is None:
         device = next(iter(w.values())).device

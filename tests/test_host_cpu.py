@@ -179,9 +179,11 @@ def test_sharded_decode_two_ranks_gloo():
 class _StubDecoderModule:
     def __init__(self, cfg, weights, prefix=""):
         import types
-        self.config = types.SimpleNamespace(**{k: v for k, v in cfg.to_dict().items()
-                                               if k not in (("frontend", "io_proj", "codebook_dim", "rvq_out_dim")
-                                                            if cfg.frontend == "split_rvq" else ("frontend", "io_proj"))})
+        # an upstream-style config: no `frontend` / `io_proj` / `rvq_out_dim` fields, and `codebook_dim` meaning the RVQ
+        # in/out width (twice the code-book row width), which must not be mistaken for the row width
+        d = {k: v for k, v in cfg.to_dict().items() if k not in ("frontend", "io_proj", "rvq_out_dim")}
+        d["codebook_dim"] = 2 * cfg.codebook_dim
+        self.config = types.SimpleNamespace(**d)
         self._sd = {prefix + k: v for k, v in weights.items()}
 
     def state_dict(self):
@@ -227,7 +229,10 @@ def test_install_hook_finds_tokenizer_and_derives_config(frontend, prefix):
     tok = _StubTokenizer(_StubDecoderModule(cfg, extra, prefix))
     model = _StubTTS(tok)
     new = install.install_decoder(model, precision="f32", device="cuda:0", decoder_factory=_FakeDecoder, max_positions=99)
-    assert new.cfg == cfg and new.precision == "f32" and new.kw == {"max_positions": 99}
+    import dataclasses
+    want = cfg if frontend == "split_rvq" else dataclasses.replace(     # the RVQ widths do not exist for a mean-embedding front end
+        cfg, codebook_dim=new.cfg.codebook_dim, rvq_out_dim=new.cfg.rvq_out_dim)
+    assert new.cfg == want and new.precision == "f32" and new.kw == {"max_positions": 99}
     assert set(new.weights) == set(w) and all(torch.equal(new.weights[k], w[k]) for k in w)
     assert model.model.speech_tokenizer.decode([0]) == ("mi355x", 24000)
     assert model.model.speech_tokenizer.reference_decode([0]) == ("reference", 24000)
@@ -246,9 +251,18 @@ def test_install_hook_refuses_mismatches():
     with pytest.raises(ValueError, match="missing or mis-shaped"):
         install.install_decoder(_StubTTS(_StubTokenizer(_StubDecoderModule(cfg, bad))), device="cuda:0", decoder_factory=_FakeDecoder)
     mod = _StubDecoderModule(cfg, w)
-    mod.config.decoder_dim = cfg.decoder_dim * 2
-    with pytest.raises(ValueError, match="decoder_dim"):
+    mod.config.head_dim = cfg.head_dim * 2                        # not a shape by itself, but q_proj's rows contradict it
+    with pytest.raises(ValueError, match="head_dim"):
         install.install_decoder(_StubTTS(_StubTokenizer(mod)), device="cuda:0", decoder_factory=_FakeDecoder)
+    mod = _StubDecoderModule(cfg, w)
+    mod.config.decoder_dim = cfg.decoder_dim * 2                  # shape-determined sizes come from the tensors alone
+    assert install.install_decoder(_StubTTS(_StubTokenizer(mod)), device="cuda:0", decoder_factory=_FakeDecoder).cfg == cfg
+    renamed = {k.replace("quantizer.", "rvq."): v for k, v in w.items()}
+    with pytest.raises(KeyError, match="rename"):
+        install.install_decoder(_StubTTS(_StubTokenizer(_StubDecoderModule(cfg, renamed))), device="cuda:0", decoder_factory=_FakeDecoder)
+    got = install.install_decoder(_StubTTS(_StubTokenizer(_StubDecoderModule(cfg, renamed))), device="cuda:0",
+                                  decoder_factory=_FakeDecoder, rename={"rvq.": "quantizer."})
+    assert got.cfg == cfg and set(got.weights) == set(w)
     cpu_model = _StubTTS(_StubTokenizer(_StubDecoderModule(cfg, w)))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         install.install_decoder(cpu_model, decoder_factory=_FakeDecoder)
@@ -352,3 +366,25 @@ def test_wav_container_and_base64_match_the_oracle():
     with pytest.raises(ValueError):
         audio.to_pcm16(torch.zeros(4))                                 # no host-side conversion path
 
+
+
+def test_built_kernels_do_not_spill_to_scratch():
+    """The contraction kernels keep LDS-DMA tiles and inline-asm residual loads in flight across compiler-visible code:
+    a scratch spill (or a reload's vmcnt(0)) inside those regions would drain the queue or read a register before its
+    load has landed.  The register report of the built objects must therefore show no scratch spill in any kernel."""
+    import glob
+    import importlib.util
+    objs = sorted(glob.glob(os.path.join(ROOT, "qwen3-tts_amd", "build", "*.hip.o")))
+    if not objs:
+        pytest.skip("object files are not in the tree (library built elsewhere)")
+    spec = importlib.util.spec_from_file_location("check_spills", os.path.join(ROOT, "tools", "check_spills.py"))
+    cs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cs)
+    seen, bad = 0, []
+    for o in objs:
+        for k in cs.kernels(o):
+            seen += 1
+            if k["vgpr_spill_count"]:
+                bad.append((os.path.basename(o), k["name"], k["vgpr_spill_count"]))
+    assert seen > 40, f"only {seen} kernels found in {len(objs)} objects"
+    assert not bad, f"kernels spilling to scratch: {bad}"
