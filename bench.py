@@ -20,13 +20,44 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def spawn_command(argv, env):
+    """`--gpus N` with N > 1 and no launcher environment: the command that starts N ranks of this script (one per GPU,
+    RCCL rendezvous on 127.0.0.1), or None when this process is already a rank (or N == 1)."""
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument("--gpus", type=int, default=1)
+    known, _ = ap.parse_known_args(argv)
+    if known.gpus <= 1 or "WORLD_SIZE" in env:
+        return None
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={known.gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def check_world(gpus: int, world: int) -> None:
+    """A run must use exactly the GPUs it was asked for: never report an N-GPU line from another number of ranks."""
+    if gpus != world:
+        raise SystemExit(f"bench.py: --gpus {gpus} but {world} rank(s) are running (WORLD_SIZE); refusing to report a mislabelled result")
+
+
+if __name__ == "__main__":
+    # Start the ranks BEFORE anything in this process can touch a GPU (torch is not even imported yet): the parent only
+    # waits for the children - rank 0 prints the JSON line on the shared stdout - and passes their exit status on.
+    _cmd = spawn_command(sys.argv[1:], os.environ)
+    if _cmd is not None:
+        sys.exit(subprocess.run(_cmd).returncode)
+
+import torch  # noqa: E402
 
 import qwen3_tts_amd as q3  # noqa: E402
 from qwen3_tts_amd.decoder import Decoder  # noqa: E402
@@ -68,9 +99,18 @@ def cpu_baseline(cfg, weights, batch: int, frames: int, threads: int) -> dict:
     wav = oracle.chunked_decode(cfg, weights, codes, cfg.chunk_size, cfg.left_context_size)
     dt = time.perf_counter() - t0
     assert wav.shape[-1] == cfg.chunked_output_length(frames)
+    # BASELINE.json configs[0] as stated: one 10 s utterance, fp32, batch 1 (one warm-up run, one timed run)
+    c0 = q3.random_codes(cfg, 1, 125, seed=0)
+    oracle.chunked_decode(cfg, weights, c0, cfg.chunk_size, cfg.left_context_size)
+    t1 = time.perf_counter()
+    w0 = oracle.chunked_decode(cfg, weights, c0, cfg.chunk_size, cfg.left_context_size)
+    dt0 = time.perf_counter() - t1
+    assert w0.shape[-1] == cfg.chunked_output_length(125)
     return {"value": round(batch * frames / cfg.frame_rate / dt, 4), "unit": "audio-sec/sec", "cores": threads, "kind": "port",
-            "sample": f"{batch} utterances x {frames / cfg.frame_rate:.1f} s ({frames} frames each), chunked decode 300+25, fp32 torch CPU "
-                      f"restatement of the decode, 1 timed run, no warm-up ({dt:.1f} s)"}
+            "sample": f"{batch} utterances x {frames / cfg.frame_rate:.1f} s ({frames} frames each) of the benchmark's workload, chunked "
+                      f"decode 300+25, fp32 torch CPU restatement of the decode, 1 timed run, no warm-up ({dt:.1f} s)",
+            "config0": {"value": round(10.0 / dt0, 4), "unit": "audio-sec/sec", "seconds": round(dt0, 2),
+                        "sample": "BASELINE.json configs[0]: 1 utterance x 10 s (125 frames), fp32, batch 1, after one warm-up run"}}
 
 
 def stream_bench(args, cfg, weights, device) -> dict:
@@ -245,18 +285,23 @@ def main() -> None:
     ap.add_argument("--utterances", type=int, default=10000)
     ap.add_argument("--streams", type=int, default=256)
     ap.add_argument("--push-frames", type=int, default=1)
+    ap.add_argument("--launch-check", action="store_true", help="every rank prints its rank / world size and exits (no GPU work)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
+    if args.launch_check:                 # plumbing check of the launcher: no GPU work
+        print(json.dumps({"rank": rank, "world": world, "gpus": args.gpus}), flush=True)
+        check_world(args.gpus, world)
+        return
     if distributed:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if args.gpus != world and rank == 0 and distributed:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+        world = dist.get_world_size()      # the ranks RCCL actually sees
+    check_world(args.gpus, world)
     device = torch.device("cuda", local_rank)
 
     cfg = q3.tiny_config() if args.tiny else q3.flagship_config()
@@ -292,7 +337,6 @@ def main() -> None:
     for _ in range(args.warmup):
         wav = step()
     barrier()
-    dec.profile(True)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record(torch.cuda.current_stream(device))
@@ -301,8 +345,23 @@ def main() -> None:
     ev1.record(torch.cuda.current_stream(device))
     barrier()
     elapsed = time.perf_counter() - t0
+    # Outside the timed region: (a) the per-kernel profile - HIP events around every launch of `psteps` further steps;
+    # (b) the same step followed by the copy of its samples to host memory (pinned double buffer), for the
+    # PCIe-inclusive rate.
+    psteps = min(args.steps, 3)
+    dec.profile(True)
+    for _ in range(psteps):
+        step()
+    torch.cuda.synchronize(device)
     prof = dec.profile_read()
     dec.profile(False)
+    dec._to_host(wav)                         # allocates the pinned staging buffers
+    torch.cuda.synchronize(device)
+    t1 = time.perf_counter()
+    for _ in range(psteps):
+        host = dec._to_host(step())
+    elapsed_d2h = (time.perf_counter() - t1) / psteps
+    assert host.shape[0] == wav.numel()
     expect = cfg.output_length(frames) if args.unchunked else cfg.chunked_output_length(frames)
     assert wav.shape == (args.batch, 1, expect), wav.shape
     assert bool(torch.isfinite(wav).all()) and float(wav.abs().max()) <= 1.0
@@ -325,7 +384,7 @@ def main() -> None:
                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(dom["kernel"]),
                     "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]),
                     "algorithmic_flops_per_launch": round(dom["flops"] / dom["launches"]),
-                    "launches_per_step": dom["launches"] // args.steps,
+                    "launches_per_step": dom["launches"] // psteps,
                     "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
                     "share_of_gpu_time": round(dom["ms"] / total_ms, 3)}
         else:
@@ -344,9 +403,11 @@ def main() -> None:
                        "frames_per_utterance": frames, "gflop_per_audio_sec": round(flops_frame * cfg.frame_rate / 1e9, 2),
                        "whole_path_tflops_per_gpu": round(whole / world, 1),
                        "whole_path_frac_of_bf16_peak": round(whole / world / PEAK_BF16_TFLOPS, 4),
-                       "gpu_event_ms_per_step": round(ev0.elapsed_time(ev1) / args.steps, 3)},
+                       "gpu_event_ms_per_step": round(ev0.elapsed_time(ev1) / args.steps, 3),
+                       "value_incl_d2h": round(args.batch * frames / cfg.frame_rate / elapsed_d2h, 1),
+                       "ms_per_step_incl_d2h": round(elapsed_d2h * 1e3, 3)},
             "roofline": roof,
-            "kernels": [{"kernel": p["kernel"], "launches": p["launches"] // args.steps, "ms_per_step": round(p["ms"] / args.steps, 3),
+            "kernels": [{"kernel": p["kernel"], "launches": p["launches"] // psteps, "ms_per_step": round(p["ms"] / psteps, 3),
                          **({"tflops": round(p["flops"] / (p["ms"] * 1e-3) / 1e12, 1)} if p["flops"] else
                             {"gbs": round(p["bytes"] / (p["ms"] * 1e-3) / 1e9, 1)})} for p in prof[:8]],
         }

@@ -1,6 +1,7 @@
 """CPU-only checks of the host side: the C ABI library loads and exports what include/q3c.h declares, the config
 struct matches the header, host-side input handling, and the multi-rank sharding/gather path over gloo."""
 import ctypes
+import json
 import os
 import re
 import subprocess
@@ -388,3 +389,30 @@ def test_built_kernels_do_not_spill_to_scratch():
                 bad.append((os.path.basename(o), k["name"], k["vgpr_spill_count"]))
     assert seen > 40, f"only {seen} kernels found in {len(objs)} objects"
     assert not bad, f"kernels spilling to scratch: {bad}"
+
+
+# ---- bench.py starts its own ranks ----------------------------------------------------------------------------------
+def test_bench_launcher_starts_one_rank_per_gpu_and_refuses_a_mislabelled_run():
+    """`python bench.py --gpus N` without a launcher environment starts N ranks itself (before torch is imported); a run
+    whose rank count differs from --gpus exits non-zero instead of printing a 1-GPU number under an N-GPU label."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cmd = bench.spawn_command(["--gpus", "4", "--steps", "7"], {})
+    assert cmd is not None and "--nproc-per-node=4" in cmd and cmd[-4:] == ["--gpus", "4", "--steps", "7"]
+    assert "127.0.0.1" in cmd and "torch.distributed.run" in cmd
+    assert bench.spawn_command(["--gpus", "1"], {}) is None
+    assert bench.spawn_command(["--gpus", "4"], {"WORLD_SIZE": "4"}) is None          # already a rank
+    with pytest.raises(SystemExit):
+        bench.check_world(8, 1)
+    bench.check_world(2, 2)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=env, capture_output=True,
+                       text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ranks = sorted(json.loads(l)["rank"] for l in r.stdout.splitlines() if l.startswith("{"))
+    assert ranks == [0, 1]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=dict(env, WORLD_SIZE="1"),
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0 and "refusing" in r.stderr
