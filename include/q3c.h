@@ -157,9 +157,10 @@ int q3c_causal_conv1d(const float* x_dev, int32_t batch, int32_t length, int32_t
  * weight [Cin][Cout][k]; Lout = (L-1)*stride - k + 2*stride. */
 int q3c_causal_tconv1d(const float* x_dev, int32_t batch, int32_t length, int32_t cin, int32_t cout, int32_t k, int32_t stride,
                        const float* weight_host, const float* bias_host, float* y_dev, int32_t precision, void* hip_stream);
-/* SnakeBeta (sib :3566-3580): y = x + 1/(exp(beta)+eps) * sin(x*exp(alpha))^2, x [rows][C]. */
+/* SnakeBeta (sib :3566-3580): y = x + 1/(exp(beta)+eps) * sin(x*exp(alpha))^2, x [rows][C].  precision BF16 runs the form the
+ * bf16 decode uses (bf16 storage on both sides, range-reduced hardware sine), F32 the parity path's polynomial sine. */
 int q3c_snake_beta(const float* x_dev, int64_t rows, int32_t channels, const float* alpha_host, const float* beta_host,
-                   float eps, float* y_dev, void* hip_stream);
+                   float eps, float* y_dev, int32_t precision, void* hip_stream);
 
 /* DecoderResidualUnit (sib :3592-3608): y = x + conv_k1(snake2(conv_k7,dilation(snake1(x)))), x / y [B][L][C], C % 8 == 0;
  * conv weights [C][C][7] and [C][C][1].  Runs the launch the decode uses for the unit: one fused launch when the

@@ -83,7 +83,7 @@ def load() -> C.CDLL:
     lib.q3c_set_tap.argtypes = [vp, i32, vp, C.c_size_t]
     lib.q3c_causal_conv1d.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp]
     lib.q3c_causal_tconv1d.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp]
-    lib.q3c_snake_beta.argtypes = [vp, C.c_int64, i32, vp, vp, C.c_float, vp, vp]
+    lib.q3c_snake_beta.argtypes = [vp, C.c_int64, i32, vp, vp, C.c_float, vp, i32, vp]
     lib.q3c_residual_unit.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp, i32, vp]
     lib.q3c_convnext_block.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp, i32, vp]
     lib.q3c_transformer.argtypes = [vp, vp, i32, i32, vp, vp, C.c_size_t, vp]

@@ -1191,16 +1191,31 @@ int q3c_causal_tconv1d(const float* x, int32_t B, int32_t L, int32_t cin, int32_
     return rc;
 }
 
-int q3c_snake_beta(const float* x, int64_t rows, int32_t C, const float* alpha, const float* beta, float eps, float* y, void* stream) {
+int q3c_snake_beta(const float* x, int64_t rows, int32_t C, const float* alpha, const float* beta, float eps, float* y, int32_t precision,
+                   void* stream) {
     if (!x || !y || !alpha || !beta || rows < 0 || C < 1) return Q3C_ERR_INVALID_ARGUMENT;
+    if (precision != Q3C_PRECISION_F32 && precision != Q3C_PRECISION_BF16) return Q3C_ERR_INVALID_ARGUMENT;
     q3c_ctx tmp;
-    Snake sn;
-    int rc = pack_snake_host(&tmp, alpha, beta, C, eps, &sn);
-    if (!rc) {
-        hipError_t e = q3_launch_snake(x, y, sn.a, sn.invb, rows, C, Q3_F32, (hipStream_t)stream);
-        if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
-        if (e != hipSuccess) rc = Q3C_ERR_HIP;
-    }
+    q3c_ctx* c = &tmp;
+    hipStream_t s = (hipStream_t)stream;
+    tmp.dtype = precision == Q3C_PRECISION_BF16 ? Q3_BF16 : Q3_F32;       // bf16: hardware sine, frequency in revolutions
+    auto run = [&]() -> int {
+        Snake sn;
+        TRY(pack_snake_host(c, alpha, beta, C, eps, &sn));
+        if (tmp.dtype == Q3_F32) {
+            LAUNCH(c, q3_launch_snake(x, y, sn.a, sn.invb, rows, C, Q3_F32, s));
+        } else {                                                           // bf16 storage on both sides, as inside the decode
+            void *xi = nullptr, *yo = nullptr;
+            const long long n = (long long)rows * C;
+            TRY(dev_alloc(c, (size_t)n * 2, &xi)); TRY(dev_alloc(c, (size_t)n * 2, &yo));
+            LAUNCH(c, q3_launch_cast_from_f32(x, xi, n, Q3_BF16, s));
+            LAUNCH(c, q3_launch_snake(xi, yo, sn.a, sn.invb, rows, C, Q3_BF16, s));
+            LAUNCH(c, q3_launch_cast_to_f32(yo, y, n, Q3_BF16, s));
+        }
+        HIPCHK(c, hipStreamSynchronize(s));
+        return 0;
+    };
+    const int rc = run();
     for (void* p : tmp.allocs) (void)hipFree(p);
     return rc;
 }

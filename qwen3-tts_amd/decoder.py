@@ -502,8 +502,8 @@ def causal_trans_conv1d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[to
     return y
 
 
-def snake_beta(x: torch.Tensor, alpha: torch.Tensor, beta: torch.Tensor, eps: float = 1e-9) -> torch.Tensor:
-    """x [..., C] (device fp32, channels-last)."""
+def snake_beta(x: torch.Tensor, alpha: torch.Tensor, beta: torch.Tensor, eps: float = 1e-9, precision: str = "f32") -> torch.Tensor:
+    """x [..., C] (device fp32, channels-last).  precision "bf16": bf16 storage and the hardware sine, as in the bf16 decode."""
     lib = _lib.load()
     Cn = x.shape[-1]
     x = x.contiguous().float()
@@ -512,7 +512,8 @@ def snake_beta(x: torch.Tensor, alpha: torch.Tensor, beta: torch.Tensor, eps: fl
     y = torch.empty_like(x)
     with torch.cuda.device(x.device):
         rc = lib.q3c_snake_beta(C.c_void_p(x.data_ptr()), x.numel() // Cn, Cn, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()),
-                                eps, C.c_void_p(y.data_ptr()), C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+                                eps, C.c_void_p(y.data_ptr()), _lib.PRECISION[precision],
+                                C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
     if rc:
         raise _lib.Q3cError(rc, "q3c_snake_beta failed")
     return y

@@ -23,10 +23,14 @@ def max_abs(ref, got):
     return float(np.abs(_host(ref) - _host(got)).max())
 
 
-def stage_report(dec, cfg, w, codes):
-    """Run one forward with taps on every stage; return [(stage name, max-abs, snr dB)] against the oracle."""
-    taps = {}
-    ref = oracle.forward(cfg, w, codes.cpu(), taps)
+def stage_report(dec, cfg, w, codes, cached=None):
+    """Run one forward with taps on every stage; return [(stage name, max-abs, snr dB)] against the oracle.
+    `cached` = (taps, ref) of an earlier oracle run on the same codes and weights."""
+    if cached is None:
+        taps = {}
+        ref = oracle.forward(cfg, w, codes.cpu(), taps)
+    else:
+        taps, ref = cached
     B, _, T = codes.shape
     stages = []
     if cfg.frontend == q3.FRONTEND_SPLIT_RVQ:
