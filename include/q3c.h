@@ -96,6 +96,18 @@ int q3c_output_length(const q3c_ctx* ctx, int32_t frames, int64_t* samples);
 int q3c_forward(q3c_ctx* ctx, const int64_t* codes_dev, int32_t batch, int32_t frames, float* wav_dev,
                 void* workspace_dev, size_t workspace_bytes, void* hip_stream);
 
+/* q3c_forward for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc).  It has no counterpart in the reference.  Same result as q3c_forward, bit for bit, but the workspace is
+ * a static device array of Q3C_STATIC_SCRATCH_BYTES inside the library (each GPU the library runs on holds its own copy
+ * until the process ends; its address on the context's device is looked up once, in q3c_finalize), and the call neither
+ * allocates nor frees device memory.  Inputs and outputs are still the caller's.  A batch x frames whose
+ * q3c_workspace_bytes exceeds Q3C_STATIC_SCRATCH_BYTES is refused with Q3C_ERR_WORKSPACE; per-kernel profiling must be off
+ * (Q3C_ERR_STATE).  Nothing in the workspace needs to start at zero - every region is written before it is read - so the
+ * previous call's contents are simply overwritten; but all contexts on one GPU share the one array: calls that overlap in
+ * time on the same GPU (two streams, two contexts, two threads) race and must be serialised by the caller. */
+#define Q3C_STATIC_SCRATCH_BYTES (64u << 20)
+int q3c_forward_static(q3c_ctx* ctx, const int64_t* codes_dev, int32_t batch, int32_t frames, float* wav_dev, void* hip_stream);
+
 /* RVQ gather-and-sum alone (mimi :1070-1077 per group, bit-exact fp32): codes [B][Q][T] ->
  * sums [B][T][G][codebook_dim] with G = 1 (semantic) + 1 (acoustic, when num_quantizers > num_semantic). */
 int q3c_rvq_dequant_f32(q3c_ctx* ctx, const int64_t* codes_dev, int32_t batch, int32_t frames, float* sums_dev,

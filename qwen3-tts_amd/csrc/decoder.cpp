@@ -11,6 +11,11 @@
 #include <string>
 #include <vector>
 
+// Workspace of q3c_forward_static: one array per GPU the library's code object is loaded on, held until the process ends.
+// Host code never uses this name as an address: q3c_finalize asks the runtime for the array's address on the context's
+// device and everything after that goes through the pointer it returned.
+static __device__ __align__(256) unsigned char q3c_static_scratch[Q3C_STATIC_SCRATCH_BYTES];
+
 namespace {
 
 struct HostTensor { std::vector<int64_t> shape; std::vector<float> data; };
@@ -65,6 +70,8 @@ struct q3c_ctx {
     Snake final_snake;
     GemmW conv_out;
 
+    int device = -1;                  // the device that was current in q3c_finalize
+    void* static_scratch = nullptr;   // address of q3c_static_scratch on that device
     int* err_flag = nullptr;
     void* zero_page = nullptr;        // 256 zero bytes: what the kernels read for rows outside a sequence
     std::map<int, std::pair<float*, size_t>> taps;
@@ -881,6 +888,13 @@ int q3c_finalize(q3c_ctx* c) {
     const int nb = k.num_upsample_rates;
     TRY(pack_snake(c, "decoder." + std::to_string(nb + 1) + ".", ch, &c->final_snake));
     TRY(pack_conv(c, "decoder." + std::to_string(nb + 2) + ".conv", 1, ch, 7, 1, dt, &c->conv_out));
+    HIPCHK(c, hipGetDevice(&c->device));
+    {   // this device's copy of the static workspace (every GPU has its own, at its own address)
+        void* sp = nullptr;
+        HIPCHK(c, hipGetSymbolAddress(&sp, HIP_SYMBOL(q3c_static_scratch)));
+        if (!sp || ((uintptr_t)sp & 255)) return fail(c, Q3C_ERR_HIP, "static workspace has no usable device address");
+        c->static_scratch = sp;
+    }
     c->staged.clear();
     c->finalized = true;
     return 0;
@@ -929,10 +943,33 @@ int q3c_rvq_dequant_f32(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, 
     return 0;
 }
 
+static int forward_impl(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, float* wav, void* ws, size_t ws_bytes, void* stream);
+
 int q3c_forward(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, float* wav, void* ws, size_t ws_bytes, void* stream) {
     if (!c) return Q3C_ERR_INVALID_ARGUMENT;
     if (!c->finalized) return fail(c, Q3C_ERR_STATE, "q3c_finalize has not run");
     if (!codes || !wav || !ws || B < 1 || T < 1) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "q3c_forward: bad argument");
+    return forward_impl(c, codes, B, T, wav, ws, ws_bytes, stream);
+}
+
+// q3c_forward on the library's static workspace: no device memory is allocated or freed here or in anything it calls
+// (launches, events and taps included: profiling, the one consumer of hipEventCreate, is refused).
+int q3c_forward_static(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, float* wav, void* stream) {
+    if (!c) return Q3C_ERR_INVALID_ARGUMENT;
+    if (!c->finalized) return fail(c, Q3C_ERR_STATE, "q3c_finalize has not run");
+    if (!codes || !wav || B < 1 || T < 1) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "q3c_forward_static: bad argument");
+    if (c->profiling) return fail(c, Q3C_ERR_STATE, "q3c_forward_static: per-kernel profiling creates events; disable it first");
+    int dev = -1;
+    HIPCHK(c, hipGetDevice(&dev));
+    if (dev != c->device) return fail(c, Q3C_ERR_STATE, "q3c_forward_static: the context's device is not current");
+    const size_t need = make_layout(c, B, T).total;
+    if (need > (size_t)Q3C_STATIC_SCRATCH_BYTES)
+        return fail(c, Q3C_ERR_WORKSPACE, "q3c_forward_static: batch x frames needs " + std::to_string(need) + " bytes of workspace, the static one holds " +
+                                              std::to_string((size_t)Q3C_STATIC_SCRATCH_BYTES) + "; use q3c_forward with a caller workspace");
+    return forward_impl(c, codes, B, T, wav, c->static_scratch, (size_t)Q3C_STATIC_SCRATCH_BYTES, stream);
+}
+
+static int forward_impl(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, float* wav, void* ws, size_t ws_bytes, void* stream) {
     const q3c_config& k = c->cfg;
     if (T > k.max_positions) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "frames exceed max_positions");
     if ((uintptr_t)ws & 255) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "workspace must be 256-byte aligned");

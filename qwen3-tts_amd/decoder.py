@@ -126,6 +126,24 @@ class Decoder:
 
     __call__ = forward
 
+    def forward_static(self, codes: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        """`forward` for callers that must not allocate device memory: codes [B, Q, T] int64 and `out` [B, 1, T*1920 - 555]
+        float32 are device tensors the caller already owns, the workspace is the library's static array
+        (q3c_forward_static; batch x frames limited by it), and nothing is allocated or freed.  Calls that overlap in time on
+        one GPU share that array and race."""
+        B, Q, T = codes.shape
+        if Q != self.cfg.num_quantizers:
+            raise ValueError(f"Expected {self.cfg.num_quantizers} layer of codes, got {tuple(codes.shape)}")
+        if codes.dtype != torch.int64 or not codes.is_contiguous() or codes.device != self.device:
+            raise ValueError("forward_static takes contiguous int64 codes already on the decoder's device")
+        if out.dtype != torch.float32 or not out.is_contiguous() or out.device != self.device or \
+                out.numel() != B * self.cfg.output_length(T):
+            raise ValueError("forward_static needs a contiguous float32 output of B * (T*total_upsample - trim) samples on the device")
+        with torch.cuda.device(self.device):
+            self._check(self._lib.q3c_forward_static(self._ctx, C.c_void_p(codes.data_ptr()), B, T, C.c_void_p(out.data_ptr()),
+                                                     self._stream()))
+        return out
+
     def chunked_decode(self, codes: torch.Tensor, chunk_size: int = 300, left_context_size: int = 25) -> torch.Tensor:
         """Same result layout as the sibling's chunked_decode (:3686-3696), but the chunks - which are independent,
         each recomputing its own left context - are batched: all chunks of equal length go through one launch
