@@ -21,7 +21,8 @@ enum Q3Act : int {
 };
 
 // h = scale[n] * act( bias[n] + sum_tap sum_k X[b, m + off0 + tap*off_step, k] * W[tap][n][k] )
-// with W2:  h <- bias2[n] + sum_j h[., j] * W2[n][j]     (fused 1x1 second contraction; N == K2, scale unused)
+// with W2:  X <- pre(X) first (per-input-channel SnakeBeta: the fused residual unit reads the RAW stream), then
+//           h <- bias2[n] + sum_j h[., j] * W2[n][j]     (fused 1x1 second contraction; N == K2, scale unused)
 // y = R[b, m, n] + h;   Y <- post(y), or with Y2:  Y <- y and Y2 <- post(y)
 // rows of X outside [0, L_in) read as zero.
 struct ConvGemmArgs {
@@ -42,6 +43,7 @@ struct ConvGemmArgs {
                                                          // seg_hist rows are carried context (read, never written); segment j,
                                                          // row r >= seg_hist goes to batch item j, row r - seg_hist of Y / Y2 / R
     const void* W2; const float* bias2;                  // [N][N] second contraction, or null
+    const float* pre_a; const float* pre_invb;           // [K] with W2: SnakeBeta applied to the staged INPUT tile in LDS
     int nxb;                                             // input buffers in LDS (2 or 3): set by the launcher
     int tile_order;                                      // 0: N tile slowest, 1: N tile fastest (set by the launcher)
     int debug;                                           // measurement aid: bit 4 = plain (not XCD-grouped) tile order

@@ -11,8 +11,10 @@
 //   ConvTranspose1d(k = 2s, stride s) taps = 2, off0 = 0, off_step = 1, N = s*Cout  (row q of [L-1, s*Cout] IS rows q*s .. q*s+s-1 of [.., Cout])
 //   ConvTranspose1d(k = s,  stride s) taps = 1, N = s*Cout
 //   Linear                            taps = 1
-//   residual unit                     FUSE2: conv k7 -> snake -> conv k1 -> + x in ONE launch (its input arrives already
-//                                     passed through the unit's first snake by the producing kernel's epilogue)
+//   residual unit                     FUSE2: snake -> conv k7 -> snake -> conv k1 -> + x in ONE launch.  It reads the RAW
+//                                     residual stream: the unit's first snake is applied to the staged input tile in LDS
+//                                     (each lane transforms the 16-byte pieces its own DMAs brought in), and the residual
+//                                     rows are re-read from the same tensor, so the unit moves two streams, not four
 //
 // A block owns a BM x BN output tile.  Per K-chunk the (BM + halo) input rows are staged ONCE in LDS and every tap
 // reads them at a row offset, so the im2col matrix never exists.  Weight tiles are staged per (K-chunk, tap) step,
@@ -217,8 +219,15 @@ convgemm_kernel(const ConvGemmArgs p) {
         int grow = g0 + row;
         int kel = kc * BK + my_c * EPC;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (id < xpieces && grow >= 0 && grow < p.L_in && kel < p.K)
+        if (id < xpieces && grow >= 0 && grow < p.L_in && kel < p.K) {
             v = *(const uint4*)(Xb + (long long)grow * p.ldx + kel);
+            if constexpr (FUSE2) {                   // the unit's first SnakeBeta, here in registers
+                TA* e = (TA*)&v;
+#pragma unroll
+                for (int i = 0; i < EPC; ++i)
+                    if (kel + i < p.K) e[i] = q3_from_f32<TA>(q3_snake<TA>(q3_to_f32(e[i]), p.pre_a[kel + i], p.pre_invb[kel + i]));
+            }
+        }
         return v;
     };
     auto x_store = [&](unsigned char* xs, int id, uint4 v) {
@@ -268,6 +277,34 @@ convgemm_kernel(const ConvGemmArgs p) {
             const unsigned long long real = (unsigned long long)sbase + xvoff0;
             const unsigned long long src = (grow >= 0 && grow < p.L_in) ? real : (unsigned long long)zero_page;
             dma16((const void*)src, xs + (unsigned)slot * 1024u);
+        }
+    };
+    // ---- FUSE2: the unit's first SnakeBeta on the staged input tile.  A lane transforms, in place, exactly the pieces
+    //      its own DMAs wrote (lane-linear destinations), after its own vmcnt wait and before the barrier that publishes
+    //      the tile - no other synchronisation.  Its channels within a K chunk are the same for every slice (the slices
+    //      are a multiple of 16 rows apart, so the source swizzle repeats); rows outside the sequence hold zeros, which
+    //      SnakeBeta maps to zero.  The per-channel parameters sit in LDS behind the spare KiB: [K] frequencies, [K] gains.
+    float* pre_lds = (float*)(smem + (spare_lds - lds0) + 1024);
+    const int pre_c0 = swz<CPR>(xrow0, my_c) * EPC;
+    auto x_snake = [&](unsigned char* xs, int it, int kc) {
+        if constexpr (FUSE2) {
+            const int slot = it * NW + wave;
+            if (it >= xi_total || slot >= x_kb) return;                  // a padding DMA: nothing staged
+            uint4* pp = (uint4*)(xs + (size_t)slot * 1024 + lane * 16);
+            uint4 v = *pp;
+            const float* pa = pre_lds + kc * BK + pre_c0;
+            const float* pb = pa + p.K;
+            float fa[EPC], fb[EPC];
+#pragma unroll
+            for (int i = 0; i < EPC; i += 4) {
+                const float4 t = *(const float4*)(pa + i), u = *(const float4*)(pb + i);
+                fa[i] = t.x; fa[i + 1] = t.y; fa[i + 2] = t.z; fa[i + 3] = t.w;
+                fb[i] = u.x; fb[i + 1] = u.y; fb[i + 2] = u.z; fb[i + 3] = u.w;
+            }
+            TA* e = (TA*)&v;
+#pragma unroll
+            for (int i = 0; i < EPC; ++i) e[i] = q3_from_f32<TA>(q3_snake<TA>(q3_to_f32(e[i]), fa[i], fb[i]));
+            *pp = v;
         }
     };
     unsigned wvoff[WITER], w2voff[WITER];
@@ -366,6 +403,15 @@ convgemm_kernel(const ConvGemmArgs p) {
         constexpr int XI_1 = (BM * CPR + NTHR - 1) / NTHR, XI_2 = ((BM + 1) * CPR + NTHR - 1) / NTHR;
         const bool static1 = lean1 && xi_total == XI_1;
         const bool static2 = lean2 && p.taps == 2 && p.off_step == 1 && xi_total == XI_2;
+        // FUSE2: the input SnakeBeta's parameters (2K floats) requested FIRST, through inline asm like the residual rows:
+        // loads retire in order, so every prologue wait below (at most the DMAs issued after this) covers them
+        u32x4 ppre;
+        const int npre4 = p.K / 2;                                       // float4 pieces: K / 4 of frequencies, then K / 4 of gains
+        if constexpr (FUSE2) {
+            const int q = tid < npre4 ? tid : 0;
+            const float* src = q < (npre4 >> 1) ? p.pre_a + 4 * q : p.pre_invb + 4 * (q - (npre4 >> 1));
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ppre) : "v"(src) : "memory");
+        }
         for (int it = 0; it < xi_total; ++it) x_dma_issue(xs_lds, it, 0);
         w_dma_issue(ws_lds, Wg, wvoff);
         inner_params();
@@ -376,6 +422,12 @@ convgemm_kernel(const ConvGemmArgs p) {
             else wait_vmcnt(WITER + ((lean1 || lean2) ? xi_total : 0));
         } else {
             wait_vmcnt(0);
+        }
+        if constexpr (FUSE2) {      // parameters -> LDS, published by a barrier of their own, then chunk 0 of the input tile
+            asm volatile("" : "+v"(ppre));
+            if (tid < npre4) *(u32x4*)(pre_lds + 4 * tid) = ppre;
+            block_barrier();
+            for (int it = 0; it < xi_total; ++it) x_snake(Xs0, it, 0);
         }
         block_barrier();
         mark(1);
@@ -430,6 +482,10 @@ convgemm_kernel(const ConvGemmArgs p) {
                 if (step == 0) wait_vmcnt(WITER + XPS);
                 else if (boundary && slack < 2) wait_vmcnt(slack == 1 ? WITER + XPS : 0);
                 else wait_vmcnt_c<WITER + 2 * XPS>();
+                if constexpr (FUSE2) {      // the next chunk's tile has landed (this wave's part): its SnakeBeta, then publish
+                    if (boundary)
+                        for (int it = 0; it < xi_total; ++it) x_snake(Xs0 + (size_t)(xb ^ 1) * XBUF, it, kc + 1);
+                }
                 block_barrier();
                 advance(boundary, XPS);
             }
@@ -475,13 +531,19 @@ convgemm_kernel(const ConvGemmArgs p) {
             unsigned wo0 = 0, wo1 = (unsigned)WBUF, wo2 = 2 * (unsigned)WBUF;      // weight buffers of step, step + 1, step + 2
             const TA* wnext = Wg + 2 * tap_stride;                                  // weight tile of step + 2
             int off_step = p.off_step;
-            auto one = [&](auto tap_tag, auto last_tag, const unsigned char* xs, unsigned xsn, const TA* xnext) {
+            // FUSE2: slice s of the next tile is requested in step s and has landed, for this wave, by the wait closing
+            // step s + 2; its SnakeBeta runs at the head of step s + 3, under that step's MFMAs, and for the slices
+            // with s + 3 past the chunk's last step right after the last step's wait.
+            auto one = [&](auto tap_tag, auto last_tag, const unsigned char* xs, unsigned xsn, const TA* xnext, unsigned char* xs_next, int kc_next) {
                 constexpr int tap = decltype(tap_tag)::value;
                 constexpr bool last = decltype(last_tag)::value;
                 constexpr bool issue_w = !last || tap + 2 < TAPS;
                 constexpr bool issue_x = !last && tap < XI;
                 const unsigned wsn = wdst_w + wo2;
                 compute(xs, Ws0 + wo0, tap * off_step, [&](int kg) {
+                    if constexpr (FUSE2 && !last && tap >= 3 && tap - 3 < XI) {
+                        if (kg == 0) x_snake(xs_next, tap - 3, kc_next);
+                    }
                     if (issue_w) {
 #pragma unroll
                         for (int q = 0; q < WITER; ++q)
@@ -498,28 +560,33 @@ convgemm_kernel(const ConvGemmArgs p) {
                 constexpr int in_flight = last ? (issue_w ? WITER : 0)
                                                : WITER + (tap < XI ? 1 : 0) + ((tap >= 1 && tap - 1 < XI) ? 1 : 0);
                 wait_vmcnt_c<in_flight>();
+                if constexpr (FUSE2 && !last && tap == TAPS - 1) {
+#pragma unroll
+                    for (int sl = TAPS - 3; sl < XI; ++sl) x_snake(xs_next, sl, kc_next);
+                }
                 block_barrier();
                 if (issue_w) wnext += ((tap + 3) % TAPS == 0) ? ((long long)BK - (TAPS - 1) * tap_stride) : tap_stride;
                 const unsigned t = wo0; wo0 = wo1; wo1 = wo2; wo2 = t;
             };
-            auto chunk = [&](auto last_tag, const unsigned char* xs, unsigned xsn, const TA* xnext) {
+            auto chunk = [&](auto last_tag, const unsigned char* xs, unsigned xsn, const TA* xnext, unsigned char* xs_next, int kc_next) {
                 // With 128 registers per wave the seven taps' fragment addresses must not be kept across chunks (they
                 // spill, and a reload's wait drains the DMA queue): hide the tap offset's loop invariance from the compiler.
                 if constexpr (waves_per_simd<TA, TO, NW, WM, WN, BKB, FUSE2>() == 4) asm volatile("" : "+s"(off_step));
-                one(std::integral_constant<int, 0>{}, last_tag, xs, xsn, xnext);
-                one(std::integral_constant<int, 1>{}, last_tag, xs, xsn, xnext);
-                one(std::integral_constant<int, 2>{}, last_tag, xs, xsn, xnext);
-                one(std::integral_constant<int, 3>{}, last_tag, xs, xsn, xnext);
-                one(std::integral_constant<int, 4>{}, last_tag, xs, xsn, xnext);
-                one(std::integral_constant<int, 5>{}, last_tag, xs, xsn, xnext);
-                one(std::integral_constant<int, 6>{}, last_tag, xs, xsn, xnext);
+                one(std::integral_constant<int, 0>{}, last_tag, xs, xsn, xnext, xs_next, kc_next);
+                one(std::integral_constant<int, 1>{}, last_tag, xs, xsn, xnext, xs_next, kc_next);
+                one(std::integral_constant<int, 2>{}, last_tag, xs, xsn, xnext, xs_next, kc_next);
+                one(std::integral_constant<int, 3>{}, last_tag, xs, xsn, xnext, xs_next, kc_next);
+                one(std::integral_constant<int, 4>{}, last_tag, xs, xsn, xnext, xs_next, kc_next);
+                one(std::integral_constant<int, 5>{}, last_tag, xs, xsn, xnext, xs_next, kc_next);
+                one(std::integral_constant<int, 6>{}, last_tag, xs, xsn, xnext, xs_next, kc_next);
             };
             int xbs = 0;
             for (int c = 0; c + 1 < nkc; ++c) {
-                chunk(std::false_type{}, Xs0 + (size_t)xbs * XBUF, xdst_w + (unsigned)((xbs ^ 1) * XBUF), xtile + (long long)(c + 1) * BK);
+                chunk(std::false_type{}, Xs0 + (size_t)xbs * XBUF, xdst_w + (unsigned)((xbs ^ 1) * XBUF), xtile + (long long)(c + 1) * BK,
+                      Xs0 + (size_t)(xbs ^ 1) * XBUF, c + 1);
                 xbs ^= 1;
             }
-            chunk(std::true_type{}, Xs0 + (size_t)xbs * XBUF, 0u, xtile);
+            chunk(std::true_type{}, Xs0 + (size_t)xbs * XBUF, 0u, xtile, Xs0, 0);
         };
         // One- and two-tap layers (linears, k = 1 convs, transposed convs) on interior tiles: the same idea with three input
         // buffers.  Chunk kc + 2's input tile is requested during chunk kc (all of it in a single-tap step, split over the
@@ -596,6 +663,10 @@ convgemm_kernel(const ConvGemmArgs p) {
                 const bool boundary = (tap + 1) == p.taps;
                 if (boundary) wait_vmcnt(more_x ? 0 : (more_w ? WITER : 0));
                 else wait_vmcnt((more_w ? WITER : 0) + (more_x ? XPS : 0));
+                if constexpr (FUSE2) {
+                    if (boundary && kc + 1 < nkc)
+                        for (int it = 0; it < xi_total; ++it) x_snake(Xs0 + (size_t)(xb + 1 == nxb ? 0 : xb + 1) * XBUF, it, kc + 1);
+                }
                 block_barrier();
                 advance(boundary, XPS);
             }
@@ -650,11 +721,12 @@ convgemm_kernel(const ConvGemmArgs p) {
     static_assert(WN % JG == 0, "slab passes must tile the wave's columns");
     float* slabA = (float*)smem + wave * (2 * SROWS * SLD);
     float* slabB = slabA + SROWS * SLD;
-    // The fused residual unit always has a residual, a consumer's snake, no SwiGLU and 16-byte-aligned rows (the
-    // launcher checks): with those known at compile time its epilogue loops have constant trip counts and no branches.
+    // The fused residual unit always has a residual, no SwiGLU and 16-byte-aligned rows (the launcher checks): with those
+    // known at compile time its epilogue loops have constant trip counts; the consumer's snake (only the last unit of a
+    // block applies one) is a wave-uniform choice per group of eight elements.
     const bool swiglu = !FUSE2 && p.act == Q3_ACT_SWIGLU;
     const int n_out = swiglu ? p.N / 2 : p.N;
-    const bool has_post = FUSE2 || p.post_a != nullptr;
+    const bool has_post = p.post_a != nullptr;
     const bool has_res = FUSE2 || Rb != nullptr;
     const bool vec_ok = FUSE2 || ((p.ldy % EPO == 0) && (!Rb || p.ldr % EPO == 0) && (n_out % EPO == 0));
     const float* obias = FUSE2 ? p.bias2 : p.bias;
@@ -1086,7 +1158,8 @@ hipError_t launch_cfg(const ConvGemmArgs& a_in, hipStream_t s) {
     const int xi_total = (HR * CPR + NTHR - 1) / NTHR;
     const int xps = (xi_total + a.taps - 1) / a.taps;
     if (xps > (BM * CPR + NTHR - 1) / NTHR || xps > 4) return hipErrorInvalidValue;      // halo too large for the staged-slice scheme
-    if (FUSE2 && (a.N > BN || !a.W2 || a.act != Q3_ACT_SNAKE || !a.epi_a || !a.epi_invb || !a.R || !a.post_a || a.ldy % 8 || a.ldr % 8 || a.N % 8))
+    if (FUSE2 && (a.N > BN || a.K != a.N || !a.W2 || a.act != Q3_ACT_SNAKE || !a.epi_a || !a.epi_invb || !a.pre_a || !a.pre_invb || !a.R ||
+                  a.ldy % 8 || a.ldr % 8 || a.N % 8))
         return hipErrorInvalidValue;
     const size_t xbuf = (size_t)((HR * CPR + 63) / 64) * 1024, wbuf = round_kb((size_t)BN * BKB), wring = 3 * wbuf + 1024;   // + a spare KiB for padding DMAs
     a.tile_order = (long long)a.taps * a.N * a.K * (long long)sizeof(TA) <= (2LL << 20) ? 1 : 0;
@@ -1095,6 +1168,7 @@ hipError_t launch_cfg(const ConvGemmArgs& a_in, hipStream_t s) {
     if (a.nxb == 3 && a.taps > 1 && round_kb(3 * xbuf) + wring > 80 * 1024 && round_kb(2 * xbuf) + wring <= 80 * 1024) a.nxb = 2;
     size_t lds = wring + round_kb(a.nxb * xbuf);
     if (FUSE2) lds = std::max(lds, 2 * wbuf + round_kb((size_t)BM * (BN * sizeof(TA) + 16)) + 1024);   // h tile over the third weight buffer and the input buffers
+    if (FUSE2) lds += round_kb((size_t)2 * a.K * sizeof(float));       // the input SnakeBeta's parameters, behind the spare KiB
     lds = std::max(lds, (size_t)NW * 2 * 16 * (32 * JG + 4) * sizeof(float));    // two wave-private 16-row epilogue slabs per wave
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const bool seg = a.seg_len > 0;

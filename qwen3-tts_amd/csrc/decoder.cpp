@@ -257,6 +257,7 @@ struct GemmOpts {
     const Snake* post = nullptr;
     void* Y2 = nullptr;               // second output: Y gets the pre-`post` value, Y2 the post value
     const GemmW* second = nullptr;    // fused 1x1 second contraction (residual unit in one launch)
+    const Snake* pre = nullptr;       // with `second`: SnakeBeta applied to the staged input tile (the unit reads the raw stream)
     // Streaming layouts.  `segmented`: the B items' rows are stacked in one row space, each item = x_hist carried rows
     // followed by its L_in new rows, and only new rows produce output.  Offsets / strides are in elements of the
     // respective tensor; a stride of 0 means dense ([B][M][n_out]).
@@ -285,7 +286,10 @@ int gemm(q3c_ctx* c, const GemmW& g, const void* X, int B, int L_in, void* Y, in
     a.Y2 = o.Y2; a.y2_batch_stride = a.y_batch_stride;
     a.zeros = c->zero_page;
     a.row_start = o.row_start;
-    if (o.second) { a.W2 = o.second->w; a.bias2 = o.second->bias; }
+    if (o.second) {
+        if (!o.pre) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "fused residual unit without its input SnakeBeta");
+        a.W2 = o.second->w; a.bias2 = o.second->bias; a.pre_a = o.pre->a; a.pre_invb = o.pre->invb;
+    }
     if (o.segmented) {
         if (M != L_in) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "segmented contraction needs as many output as input rows");
         const size_t eo = esize(out_dtype);
@@ -309,8 +313,9 @@ int gemm(q3c_ctx* c, const GemmW& g, const void* X, int B, int L_in, void* Y, in
         }
     }
     // algorithmic bytes: input, weights, and each output / residual tensor once
+    // (the fused unit's residual rows are rows of its input tensor, read moments before: not a second stream)
     const double abytes = (double)B * L_in * g.K * esize(g.in_dtype) + (double)g.taps * g.N * g.K * esize(g.in_dtype) +
-                          (double)B * M * n_out * esize(out_dtype) * (1 + (o.Y2 ? 1 : 0) + (o.R ? 1 : 0));
+                          (double)B * M * n_out * esize(out_dtype) * (1 + (o.Y2 ? 1 : 0) + ((o.R && !o.second) ? 1 : 0));
     ProfScope ps(c, s, pname, 2.0 * B * M * (double)a.N * (a.K * a.taps + (o.second ? a.N : 0)), abytes);
     hipError_t e = q3_launch_convgemm(a, g.in_dtype, out_dtype, s);
     if (e != hipSuccess) return fail(c, Q3C_ERR_HIP, std::string("convgemm launch: ") + hipGetErrorString(e));
@@ -628,16 +633,24 @@ int stream_sequence(q3c_stream_pool* P, int S, int n, bool run, const StreamPlan
         const int Lr = L * b.rate;
         const int* rs_t = rs_all + (size_t)(2 * i) * S;
         const int* rs_u = rs_all + (size_t)(2 * i + 1) * S;
-        const size_t o_raw = alloc((size_t)S * Lr * ch * es);
         const bool fuse = c->fuse_units && q3_convgemm_fusable(ch, dt);
+        // unfused units keep a raw residual stream beside the snaked tensors and an h tensor between their two convs;
+        // fused units read and write the raw stream only (their [carried | new] tensors ARE the residual stream)
+        const size_t o_raw = fuse ? 0 : alloc((size_t)S * Lr * ch * es);
         const size_t o_h = fuse ? 0 : alloc((size_t)S * Lr * ch * es);
         void* raw = ws + o_raw;
         SBuf u_in = tensor(6 * k.dilations[0], Lr, ch, es);
         if (run) {
             // [previous | new] input rows: group j of r output rows needs rows j-1 and j
-            GemmOpts g; g.segmented = true; g.x_hist = 1; g.off_shift = -1; g.post = &b.first_act_tiled; g.row_start = rs_t;
-            g.Y2 = ptr(u_in); g.y2_off = new_rows_off(u_in); g.y2_bstride = item_stride(u_in);
-            TRY(gemm(c, b.tconv, ptr(t_in), S, L, raw, L, dt, g, s));
+            GemmOpts g; g.segmented = true; g.x_hist = 1; g.off_shift = -1; g.row_start = rs_t;
+            if (fuse) {
+                g.y_off = new_rows_off(u_in); g.y_bstride = item_stride(u_in);
+                TRY(gemm(c, b.tconv, ptr(t_in), S, L, ptr(u_in), L, dt, g, s));
+            } else {
+                g.post = &b.first_act_tiled;
+                g.Y2 = ptr(u_in); g.y2_off = new_rows_off(u_in); g.y2_bstride = item_stride(u_in);
+                TRY(gemm(c, b.tconv, ptr(t_in), S, L, raw, L, dt, g, s));
+            }
         }
         L = Lr;
         for (size_t j = 0; j < b.units.size(); ++j) {
@@ -646,14 +659,18 @@ int stream_sequence(q3c_stream_pool* P, int S, int n, bool run, const StreamPlan
             const Snake* post = !last ? &b.units[j + 1].a1 : ((i + 1 < nb) ? &c->blocks[i + 1].head : &c->final_snake);
             SBuf next = last ? tensor(i + 1 < nb ? 1 : 6, L, ch, es) : tensor(6 * k.dilations[j + 1], L, ch, es);
             if (run) {
-                GemmOpts g; g.segmented = true; g.R = raw; g.post = post; g.row_start = rs_u;
-                void* Y;
-                if (last) { Y = ptr(next); g.y_off = new_rows_off(next); g.y_bstride = item_stride(next); }
-                else { Y = raw; g.Y2 = ptr(next); g.y2_off = new_rows_off(next); g.y2_bstride = item_stride(next); }
                 if (fuse) {
-                    g.x_hist = u_in.hist; g.act = Q3_ACT_SNAKE; g.epi = &u.a2; g.second = &u.c2;
-                    TRY(gemm(c, u.c1, ptr(u_in), S, L, Y, L, dt, g, s));
+                    GemmOpts g; g.segmented = true; g.row_start = rs_u; g.x_hist = u_in.hist;
+                    g.act = Q3_ACT_SNAKE; g.epi = &u.a2; g.second = &u.c2; g.pre = &u.a1;
+                    g.R = ptr(u_in); g.r_off = new_rows_off(u_in); g.r_bstride = item_stride(u_in);
+                    g.y_off = new_rows_off(next); g.y_bstride = item_stride(next);
+                    if (last) g.post = post;
+                    TRY(gemm(c, u.c1, ptr(u_in), S, L, ptr(next), L, dt, g, s));
                 } else {
+                    GemmOpts g; g.segmented = true; g.R = raw; g.post = post; g.row_start = rs_u;
+                    void* Y;
+                    if (last) { Y = ptr(next); g.y_off = new_rows_off(next); g.y_bstride = item_stride(next); }
+                    else { Y = raw; g.Y2 = ptr(next); g.y2_off = new_rows_off(next); g.y2_bstride = item_stride(next); }
                     GemmOpts g1; g1.segmented = true; g1.x_hist = u_in.hist; g1.act = Q3_ACT_SNAKE; g1.epi = &u.a2;
                     TRY(gemm(c, u.c1, ptr(u_in), S, L, ws + o_h, L, dt, g1, s));
                     TRY(gemm(c, u.c2, ws + o_h, S, L, Y, L, dt, g, s));
@@ -1044,24 +1061,26 @@ static int forward_impl(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, 
         const int Lq = L - 1;
         ch /= 2;
         void* raw = free_bufs[0]; void* sn = free_bufs[1]; void* sp = free_bufs[2];
+        const bool fuse = c->fuse_units && q3_convgemm_fusable(ch, dt);
         {
-            GemmOpts g; g.post = &b.first_act_tiled; g.Y2 = sn;
+            // fused units read the raw stream and apply their own first SnakeBeta: the transposed conv then writes ONE tensor
+            GemmOpts g;
+            if (!fuse) { g.post = &b.first_act_tiled; g.Y2 = sn; }
             TRY(gemm(c, b.tconv, cur, B, L, raw, Lq, dt, g, s));              // [B, L-1, r*ch] == [B, (L-1)*r, ch]
         }
         L = Lq * b.rate;
-        const bool fuse = c->fuse_units && q3_convgemm_fusable(ch, dt);
         for (size_t j = 0; j < b.units.size(); ++j) {
             const Unit& u = b.units[j];
             const bool last = j + 1 == b.units.size();
             const Snake* post = !last ? &b.units[j + 1].a1 : ((i + 1 < c->blocks.size()) ? &c->blocks[i + 1].head : &c->final_snake);
             if (fuse) {
-                // conv k7 -> snake -> conv k1 -> + raw in one launch; it reads `sn` with a halo, so the snaked output
-                // goes to the spare buffer; the raw stream is updated in place (each element is read and written by
-                // the same lane)
-                GemmOpts g; g.act = Q3_ACT_SNAKE; g.epi = &u.a2; g.second = &u.c2; g.R = raw; g.post = post;
-                if (last) { TRY(gemm(c, u.c1, sn, B, L, sp, L, dt, g, s)); }
-                else { g.Y2 = sp; TRY(gemm(c, u.c1, sn, B, L, raw, L, dt, g, s)); }
-                std::swap(sn, sp);
+                // snake -> conv k7 -> snake -> conv k1 -> + x in one launch on the RAW stream: one tensor in (read with a
+                // halo, so the result goes to the other buffer), one tensor out; only the block's last unit applies a
+                // consumer's SnakeBeta (the next block's head, or the final one), to its single output
+                GemmOpts g; g.act = Q3_ACT_SNAKE; g.epi = &u.a2; g.second = &u.c2; g.pre = &u.a1; g.R = raw;
+                if (last) g.post = post;
+                TRY(gemm(c, u.c1, raw, B, L, sn, L, dt, g, s));
+                if (!last) std::swap(raw, sn);     // the last unit's (snaked) output stays in `sn`: the block's output
             } else {
                 GemmOpts g1; g1.act = Q3_ACT_SNAKE; g1.epi = &u.a2;
                 TRY(gemm(c, u.c1, sn, B, L, sp, L, dt, g1, s));
@@ -1277,25 +1296,20 @@ int q3c_residual_unit(const float* x, int32_t B, int32_t L, int32_t C, int32_t d
         tmp.staged["c2.weight"] = HostTensor{{C, C, 1}, std::vector<float>(w2, w2 + (size_t)C * C)};
         tmp.staged["c2.bias"] = HostTensor{{C}, std::vector<float>(b2, b2 + C)};
         GemmW c1, c2;
-        Snake a1, a2, ident;
+        Snake a1, a2;
         TRY(pack_conv(c, "c1", C, C, 7, dilation, dt, &c1));
         TRY(pack_conv(c, "c2", C, C, 1, 1, dt, &c2));
         TRY(pack_snake_host(c, alpha1, beta1, C, eps, &a1));
         TRY(pack_snake_host(c, alpha2, beta2, C, eps, &a2));
-        // a consumer's SnakeBeta with frequency 0 and gain 0 is the identity: v + 0 * sin^2(0)
-        std::vector<float> zeros((size_t)C, 0.f);
-        ident.C = C;
-        TRY(upload_f32(c, zeros, &ident.a));
-        TRY(upload_f32(c, zeros, &ident.invb));
         TRY(ensure_zero_page(c));
         void *raw = nullptr, *sn = nullptr, *h = nullptr, *out = nullptr;
         TRY(dev_alloc(c, n * es, &raw)); TRY(dev_alloc(c, n * es, &sn)); TRY(dev_alloc(c, n * es, &h)); TRY(dev_alloc(c, n * es, &out));
         LAUNCH(c, q3_launch_cast_from_f32(x, raw, (long long)n, dt, s));
-        LAUNCH(c, q3_launch_snake(raw, sn, a1.a, a1.invb, (long long)B * L, C, dt, s));
-        if (q3_convgemm_fusable(C, dt)) {
-            GemmOpts g; g.act = Q3_ACT_SNAKE; g.epi = &a2; g.second = &c2; g.R = raw; g.post = &ident; g.Y2 = h;
-            TRY(gemm(c, c1, sn, B, L, out, L, dt, g, s));
+        if (q3_convgemm_fusable(C, dt)) {       // the fused launch reads the raw input and applies the first SnakeBeta itself
+            GemmOpts g; g.act = Q3_ACT_SNAKE; g.epi = &a2; g.second = &c2; g.pre = &a1; g.R = raw;
+            TRY(gemm(c, c1, raw, B, L, out, L, dt, g, s));
         } else {
+            LAUNCH(c, q3_launch_snake(raw, sn, a1.a, a1.invb, (long long)B * L, C, dt, s));
             GemmOpts g1; g1.act = Q3_ACT_SNAKE; g1.epi = &a2;
             TRY(gemm(c, c1, sn, B, L, h, L, dt, g1, s));
             GemmOpts g2; g2.R = raw;
