@@ -129,14 +129,15 @@ def stream_bench(args, cfg, weights, device) -> dict:
             pool.push_raw(torch.tensor(sub, dtype=torch.int32, device=device), q3.random_codes(cfg, len(sub), 1, seed=100 + j).to(device))
     codes = [q3.random_codes(cfg, S, n, seed=2 + j).to(device) for j in range(8)]
     out = torch.empty((S, n * cfg.total_upsample), dtype=torch.float32, device=device)
-    for j in range(args.warmup):
-        pool.push_raw(ids_dev, codes[j % 8], out)
+    use_graph = not args.no_graph       # the push replayed from a HIP graph per (ids, codes, out) buffer set: 8 graphs here
+    for j in range(max(args.warmup, 8)):
+        pool.push_raw(ids_dev, codes[j % 8], out, graph=use_graph)
     torch.cuda.synchronize(device)
     lat = []
     t_all = time.perf_counter()
     for j in range(args.steps):
         t0 = time.perf_counter()
-        pool.push_raw(ids_dev, codes[j % 8], out)
+        pool.push_raw(ids_dev, codes[j % 8], out, graph=use_graph)
         torch.cuda.synchronize(device)
         lat.append((time.perf_counter() - t0) * 1e3)
     elapsed = time.perf_counter() - t_all
@@ -157,7 +158,7 @@ def stream_bench(args, cfg, weights, device) -> dict:
                                    f"state carried in HBM, staggered positions, flagship architecture, random-init weights",
                        "p50_ms": round(float(np.percentile(lat, 50)), 3), "p99_ms": round(float(np.percentile(lat, 99)), 3),
                        "max_ms": round(float(lat.max()), 3), "real_time_factor": round(n * 80.0 / float(np.percentile(lat, 99)), 1),
-                       "state_bytes_per_stream": pool.state_bytes_per_stream},
+                       "state_bytes_per_stream": pool.state_bytes_per_stream, "hip_graph": use_graph},
             "kernels": [{"kernel": p["kernel"], "launches": p["launches"], "ms_per_step": round(p["ms"], 3)} for p in prof[:8]]}
 
 
@@ -285,6 +286,7 @@ def main() -> None:
     ap.add_argument("--utterances", type=int, default=10000)
     ap.add_argument("--streams", type=int, default=256)
     ap.add_argument("--push-frames", type=int, default=1)
+    ap.add_argument("--no-graph", action="store_true", help="stream workload: plain launches instead of the HIP-graph replay")
     ap.add_argument("--launch-check", action="store_true", help="every rank prints its rank / world size and exits (no GPU work)")
     args = ap.parse_args()
 

@@ -135,8 +135,17 @@ int q3c_set_tap(q3c_ctx* ctx, int32_t stage, float* dev_buffer, size_t capacity_
  * their positions: codes [S][Q][n] int64 -> wav [S][n*total_upsample] fp32.  Over a stream's life the concatenated
  * pushes are `trim` blank samples (zeros, at the start of its first push) followed by the un-chunked forward's output
  * for the frames pushed so far.  Errors found on the device (slot id outside the pool, more than max_positions
- * frames in one stream) are reported by q3c_check_errors.  The first push with a new (S, n) pair allocates a small
- * descriptor table; later ones allocate nothing.  Destroy pools before their context. */
+ * frames in one stream) are reported by q3c_check_errors.  q3c_stream_workspace_bytes(S, n) sizes the workspace of such a push
+ * AND prepares it (a small descriptor table in device memory, allocated once per (S, n) pair); q3c_stream_push itself never
+ * allocates or synchronises and returns Q3C_ERR_STATE for a pair that has not been prepared.  Destroy pools before their
+ * context.
+ *
+ * q3c_stream_push_graph is the same push replayed from a HIP graph (about 90 small launches become one graph launch).  A
+ * graph's kernel nodes hold their operand addresses, so graphs are cached per (S, n, slots_dev, codes_dev, wav_dev,
+ * workspace_dev): the first call with a new combination records the launch sequence on a side stream and instantiates it
+ * (host work of a few milliseconds), later calls only launch it; callers therefore keep a fixed set of buffers and refill
+ * them.  Up to 32 combinations per (S, n) are cached, further ones run as a plain push; while per-kernel profiling or a tap
+ * is on, or while the caller's own stream is capturing, it is a plain push too. */
 typedef struct q3c_stream_pool q3c_stream_pool;
 int q3c_stream_pool_create(q3c_ctx* ctx, int32_t capacity, q3c_stream_pool** out);
 void q3c_stream_pool_destroy(q3c_stream_pool* pool);
@@ -145,6 +154,8 @@ int q3c_stream_reset(q3c_stream_pool* pool, const int32_t* slots_dev, int32_t co
 int q3c_stream_workspace_bytes(q3c_stream_pool* pool, int32_t streams, int32_t frames, size_t* bytes);
 int q3c_stream_push(q3c_stream_pool* pool, const int32_t* slots_dev, int32_t streams, const int64_t* codes_dev, int32_t frames,
                     float* wav_dev, void* workspace_dev, size_t workspace_bytes, void* hip_stream);
+int q3c_stream_push_graph(q3c_stream_pool* pool, const int32_t* slots_dev, int32_t streams, const int64_t* codes_dev, int32_t frames,
+                          float* wav_dev, void* workspace_dev, size_t workspace_bytes, void* hip_stream);
 
 /* -- per-kernel timing (no counterpart in the reference; used by bench.py for the roofline figures) -----------
  * While enabled, every kernel launch of q3c_forward is bracketed by a pair of HIP events on the caller's stream.

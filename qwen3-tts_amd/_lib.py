@@ -22,7 +22,7 @@ EXPORTS = ["q3c_create", "q3c_destroy", "q3c_last_error", "q3c_version", "q3c_lo
            "q3c_workspace_bytes", "q3c_output_length", "q3c_forward", "q3c_forward_static", "q3c_rvq_dequant_f32", "q3c_check_errors",
            "q3c_set_tap", "q3c_causal_conv1d", "q3c_causal_tconv1d", "q3c_snake_beta", "q3c_profile_enable",
            "q3c_profile_read", "q3c_stream_pool_create", "q3c_stream_pool_destroy", "q3c_stream_state_bytes",
-           "q3c_stream_reset", "q3c_stream_workspace_bytes", "q3c_stream_push", "q3c_residual_unit", "q3c_convnext_block",
+           "q3c_stream_reset", "q3c_stream_workspace_bytes", "q3c_stream_push", "q3c_stream_push_graph", "q3c_residual_unit", "q3c_convnext_block",
            "q3c_transformer", "q3c_wav_to_pcm16"]
 
 
@@ -99,6 +99,7 @@ def load() -> C.CDLL:
     lib.q3c_stream_reset.argtypes = [vp, vp, i32, vp]
     lib.q3c_stream_workspace_bytes.argtypes = [vp, i32, i32, C.POINTER(C.c_size_t)]
     lib.q3c_stream_push.argtypes = [vp, vp, i32, vp, i32, vp, vp, C.c_size_t, vp]
+    lib.q3c_stream_push_graph.argtypes = [vp, vp, i32, vp, i32, vp, vp, C.c_size_t, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("q3c_destroy", "q3c_last_error", "q3c_version", "q3c_stream_pool_destroy"):

@@ -471,7 +471,10 @@ int validate_config(q3c_ctx* c) {
 // the leading rows of every later stage do not exist: they are stored as zeros (exactly the zero padding the causal
 // convs of the un-chunked forward see there) and the first `trim` samples of the first push are blank.
 // =========================================================================================================
-struct StreamPlan { size_t ws_bytes = 0; Q3CarryDesc* descs = nullptr; int ndesc = 0; };
+// a captured push: the launch sequence of one (S, n) with these exact operand addresses baked into its kernel nodes
+struct PushGraph { const void *slots, *codes, *wav, *ws; hipGraphExec_t exec; };
+struct StreamPlan { size_t ws_bytes = 0; Q3CarryDesc* descs = nullptr; int ndesc = 0; std::vector<PushGraph> graphs; };
+constexpr size_t MAX_GRAPHS_PER_PLAN = 32;
 
 }  // namespace
 
@@ -483,6 +486,7 @@ struct q3c_stream_pool {
     int* pos = nullptr;
     std::map<std::pair<int, int>, StreamPlan> plans;
     std::vector<void*> allocs;
+    hipStream_t capture_stream = nullptr;   // side stream the push graphs are captured on (the legacy default stream cannot capture)
 };
 
 namespace {
@@ -691,9 +695,12 @@ int stream_sequence(q3c_stream_pool* P, int S, int n, bool run, const StreamPlan
     return 0;
 }
 
-int stream_plan(q3c_stream_pool* P, int S, int n, const StreamPlan** out) {
+int stream_plan(q3c_stream_pool* P, int S, int n, StreamPlan** out, bool create) {
     q3c_ctx* c = P->c;
     auto it = P->plans.find({S, n});
+    if (it == P->plans.end() && !create)
+        return fail(c, Q3C_ERR_STATE, "no plan for this (streams, frames) pair: call q3c_stream_workspace_bytes(streams, frames) first "
+                                      "(it sizes the workspace and allocates the push's descriptor table; q3c_stream_push allocates nothing)");
     if (it == P->plans.end()) {
         std::vector<Q3CarryDesc> descs;
         StreamPlan pl;
@@ -1155,6 +1162,9 @@ int q3c_stream_pool_create(q3c_ctx* c, int32_t capacity, q3c_stream_pool** out) 
 
 void q3c_stream_pool_destroy(q3c_stream_pool* P) {
     if (!P) return;
+    for (auto& kv : P->plans)
+        for (auto& g : kv.second.graphs) (void)hipGraphExecDestroy(g.exec);
+    if (P->capture_stream) (void)hipStreamDestroy(P->capture_stream);
     for (void* q : P->allocs) (void)hipFree(q);
     delete P;
 }
@@ -1176,8 +1186,8 @@ int q3c_stream_reset(q3c_stream_pool* P, const int32_t* slots, int32_t count, vo
 int q3c_stream_workspace_bytes(q3c_stream_pool* P, int32_t S, int32_t n, size_t* bytes) {
     if (!P || !bytes) return Q3C_ERR_INVALID_ARGUMENT;
     if (S < 1 || n < 1) return fail(P->c, Q3C_ERR_INVALID_ARGUMENT, "streams and frames must be >= 1");
-    const StreamPlan* pl;
-    TRY(stream_plan(P, S, n, &pl));
+    StreamPlan* pl;
+    TRY(stream_plan(P, S, n, &pl, true));
     *bytes = pl->ws_bytes;
     return 0;
 }
@@ -1189,10 +1199,53 @@ int q3c_stream_push(q3c_stream_pool* P, const int32_t* slots, int32_t S, const i
     if (!slots || !codes || !wav || !ws || S < 1 || n < 1) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "q3c_stream_push: bad argument");
     if (S > P->capacity) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "more streams in one push than the pool holds");
     if ((uintptr_t)ws & 255) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "workspace must be 256-byte aligned");
-    const StreamPlan* pl;
-    TRY(stream_plan(P, S, n, &pl));
+    StreamPlan* pl;
+    TRY(stream_plan(P, S, n, &pl, false));
     if (ws_bytes < pl->ws_bytes) return fail(c, Q3C_ERR_WORKSPACE, "workspace too small: need " + std::to_string(pl->ws_bytes));
     return stream_sequence(P, S, n, true, pl, slots, codes, wav, (char*)ws, (hipStream_t)stream, nullptr, nullptr, nullptr);
+}
+
+// The same push replayed from a HIP graph.  A push at frame rate is ~90 small launches; replaying them as one graph takes
+// the per-launch host work and most of the gaps between dependent kernels out of the latency.  Kernel nodes hold their
+// operand addresses, so a graph is keyed by (streams, frames) AND the four buffers; the first call with a new key records
+// the sequence on a side stream (nothing runs during recording) and instantiates it, later calls only launch it.
+int q3c_stream_push_graph(q3c_stream_pool* P, const int32_t* slots, int32_t S, const int64_t* codes, int32_t n, float* wav, void* ws,
+                          size_t ws_bytes, void* stream) {
+    if (!P) return Q3C_ERR_INVALID_ARGUMENT;
+    q3c_ctx* c = P->c;
+    if (!slots || !codes || !wav || !ws || S < 1 || n < 1) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "q3c_stream_push_graph: bad argument");
+    if (S > P->capacity) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "more streams in one push than the pool holds");
+    if ((uintptr_t)ws & 255) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "workspace must be 256-byte aligned");
+    StreamPlan* pl;
+    TRY(stream_plan(P, S, n, &pl, false));
+    if (ws_bytes < pl->ws_bytes) return fail(c, Q3C_ERR_WORKSPACE, "workspace too small: need " + std::to_string(pl->ws_bytes));
+    hipStream_t s = (hipStream_t)stream;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (s) HIPCHK(c, hipStreamIsCapturing(s, &st));
+    // per-kernel profiling records events between launches, and a caller who is capturing already gets the plain sequence
+    if (c->profiling || !c->taps.empty() || st != hipStreamCaptureStatusNone)
+        return stream_sequence(P, S, n, true, pl, slots, codes, wav, (char*)ws, s, nullptr, nullptr, nullptr);
+    for (const PushGraph& g : pl->graphs)
+        if (g.slots == slots && g.codes == codes && g.wav == wav && g.ws == ws) {
+            HIPCHK(c, hipGraphLaunch(g.exec, s));
+            return 0;
+        }
+    if (pl->graphs.size() >= MAX_GRAPHS_PER_PLAN)       // a caller that never reuses its buffers gains nothing from graphs
+        return stream_sequence(P, S, n, true, pl, slots, codes, wav, (char*)ws, s, nullptr, nullptr, nullptr);
+    if (!P->capture_stream) HIPCHK(c, hipStreamCreateWithFlags(&P->capture_stream, hipStreamNonBlocking));
+    HIPCHK(c, hipStreamBeginCapture(P->capture_stream, hipStreamCaptureModeThreadLocal));
+    const int rc = stream_sequence(P, S, n, true, pl, slots, codes, wav, (char*)ws, P->capture_stream, nullptr, nullptr, nullptr);
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(P->capture_stream, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess || !graph) return fail(c, Q3C_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    PushGraph pg{slots, codes, wav, ws, nullptr};
+    const hipError_t e2 = hipGraphInstantiate(&pg.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e2 != hipSuccess) return fail(c, Q3C_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e2));
+    pl->graphs.push_back(pg);
+    HIPCHK(c, hipGraphLaunch(pg.exec, s));
+    return 0;
 }
 
 // ---- single operators ---------------------------------------------------------------------------------------

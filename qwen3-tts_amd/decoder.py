@@ -430,9 +430,11 @@ class StreamPool:
     def frames_pushed(self, sid: int) -> int:
         return self._frames[sid]
 
-    def push_raw(self, ids_dev: torch.Tensor, codes: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def push_raw(self, ids_dev: torch.Tensor, codes: torch.Tensor, out: Optional[torch.Tensor] = None, graph: bool = False) -> torch.Tensor:
         """The launch sequence alone: ids_dev int32 [S] and codes int64 [S, Q, n] on the device -> [S, n*1920] float32
-        (a stream's first push starts with 555 blank samples).  No host bookkeeping and no synchronisation."""
+        (a stream's first push starts with 555 blank samples).  No host bookkeeping and no synchronisation.
+        graph=True replays the push from a HIP graph cached for these exact tensors (q3c_stream_push_graph): meant for a
+        serving loop that refills a fixed set of `ids_dev` / `codes` / `out` buffers."""
         dec = self.dec
         S, Q, n = codes.shape
         up = dec.cfg.total_upsample
@@ -445,9 +447,9 @@ class StreamPool:
                 self._ws = None
                 self._ws = torch.empty(need.value + 256, dtype=torch.uint8, device=dec.device)
             base = (self._ws.data_ptr() + 255) // 256 * 256
-            dec._check(self._lib.q3c_stream_push(self._pool, C.c_void_p(ids_dev.data_ptr()), S, C.c_void_p(codes.data_ptr()), n,
-                                                 C.c_void_p(out.data_ptr()), C.c_void_p(base),
-                                                 self._ws.numel() - (base - self._ws.data_ptr()), dec._stream()))
+            fn = self._lib.q3c_stream_push_graph if graph else self._lib.q3c_stream_push
+            dec._check(fn(self._pool, C.c_void_p(ids_dev.data_ptr()), S, C.c_void_p(codes.data_ptr()), n, C.c_void_p(out.data_ptr()),
+                          C.c_void_p(base), self._ws.numel() - (base - self._ws.data_ptr()), dec._stream()))
         return out
 
     def push(self, ids: Sequence[int], codes: torch.Tensor, check: bool = False) -> List[torch.Tensor]:

@@ -168,3 +168,29 @@ def test_flagship_bf16_streams_track_the_bulk_forward():
     print(f"flagship bf16 streaming vs bulk: rms(diff) / rms = {rel:.4f}")
     assert rel <= 10 ** (-30 / 20), rel
 
+
+
+def test_graph_replayed_push_equals_plain_push():
+    """q3c_stream_push_graph: the push recorded once per buffer set and replayed must produce the bits of the plain launch
+    sequence, step after step (state carried between replays), for two alternating code buffers and a second (S, n)."""
+    cfg = q3.tiny_config("split_rvq")
+    dec, _ = _decoder(cfg, precision="bf16")
+    S = 5
+    pa, pb = dec.open_streams(S), dec.open_streams(S)
+    ia = torch.tensor(pa.open_many(S), dtype=torch.int32, device="cuda")
+    ib = torch.tensor(pb.open_many(S), dtype=torch.int32, device="cuda")
+    for n, steps in ((1, 12), (3, 4)):
+        bufs = [torch.empty((S, cfg.num_quantizers, n), dtype=torch.int64, device="cuda") for _ in range(2)]
+        out_g = torch.empty((S, n * cfg.total_upsample), dtype=torch.float32, device="cuda")
+        for t in range(steps):
+            codes = q3.random_codes(cfg, S, n, seed=100 * n + t).cuda()
+            bufs[t % 2].copy_(codes)
+            got = pa.push_raw(ia, bufs[t % 2], out_g, graph=True)
+            want = pb.push_raw(ib, codes)
+            assert got.data_ptr() == out_g.data_ptr()
+            assert torch.equal(got, want), (n, t, max_abs(got, want))
+    # a push that was never prepared is refused instead of allocating behind the caller's back
+    import ctypes as C
+    rc = dec._lib.q3c_stream_push(pa._pool, C.c_void_p(ia.data_ptr()), 2, C.c_void_p(bufs[0].data_ptr()), 7, C.c_void_p(out_g.data_ptr()),
+                                  C.c_void_p((pa._ws.data_ptr() + 255) // 256 * 256), 1 << 20, dec._stream())
+    assert rc == -3 and b"q3c_stream_workspace_bytes" in dec._lib.q3c_last_error(dec._ctx)

@@ -416,3 +416,34 @@ def test_bench_launcher_starts_one_rank_per_gpu_and_refuses_a_mislabelled_run():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=dict(env, WORLD_SIZE="1"),
                        capture_output=True, text=True, timeout=240)
     assert r.returncode != 0 and "refusing" in r.stderr
+
+
+# ---- REST surface: request shaping and schemas (no GPU) -----------------------------------------------------------------
+def test_server_schemas_and_request_shaping_follow_the_reference():
+    """Field names, defaults and bounds of reference schemas.py:10-35; sentence splitting and the auto-split rule of
+    reference server.py:74-91, 205-211; the SSE wire format of API_GUIDE.md:138-161."""
+    import pydantic
+    from qwen3_tts_amd import server
+    p = server.GenerationParams()
+    assert (p.max_new_tokens, p.temperature, p.top_k, p.top_p, p.repetition_penalty, p.do_sample) == (2048, 0.9, 50, 1.0, 1.05, True)
+    for bad in ({"max_new_tokens": 0}, {"max_new_tokens": 4097}, {"temperature": 2.5}, {"top_k": 101}, {"top_p": 1.5}, {"repetition_penalty": 0.9}):
+        with pytest.raises(pydantic.ValidationError):
+            server.GenerationParams(**bad)
+    r = server.VoiceCloneRequest(text="a", ref_audio="x.mp3", ref_text="t")
+    assert r.language == "Auto" and r.x_vector_only_mode is True and r.split_sentences is None and r.seed is None
+    assert server.VoiceCloneRequest(text=["a", "b"], ref_audio=["x", "y"], ref_text=["t", "u"]).text == ["a", "b"]
+    with pytest.raises(pydantic.ValidationError):
+        server.VoiceCloneRequest(text="a")
+    assert server.get_generation_kwargs() == {"max_new_tokens": 2048, "temperature": 0.9, "top_k": 50, "top_p": 1.0,
+                                              "repetition_penalty": 1.05, "do_sample": True}
+    assert server.split_into_sentences("One. Two!  Three?? Four") == ["One", "Two", "Three", "Four"]
+    assert server.split_into_sentences("no terminator") == ["no terminator"]
+    assert server.split_into_sentences("v1.5 is out") == ["v1.5 is out"]              # a dot without white space does not split
+    assert not server.should_split("short. text.", None) and server.should_split("a. b. c. d. e. f. g", None)
+    assert server.should_split("x" * 501, None) and not server.should_split("x" * 501, False) and server.should_split("a", True)
+    assert server.model_key_for("0.6b") == "base_0.6b" and server.model_key_for("1.7b") == "base_1.7b" and server.model_key_for("big") == "base"
+    assert server.sse_event("meta", {"status": "generating", "text": "안녕"}) == 'event: meta\ndata: {"status": "generating", "text": "안녕"}\n\n'
+    cfg = q3.tiny_config()
+    src = server.hashed_code_source(cfg)
+    a, b = src(text="hello", seed=1), src(text="hello", seed=1)
+    assert torch.equal(a, b) and a.shape[0] == cfg.num_quantizers and not torch.equal(a, src(text="hello", seed=2))
