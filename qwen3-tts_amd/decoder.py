@@ -28,6 +28,47 @@ def rope_inv_freq(cfg: DecoderConfig) -> torch.Tensor:
     return 1.0 / (cfg.rope_theta ** (torch.arange(0, d, 2, dtype=torch.float) / d))
 
 
+_STAGE: Dict[int, tuple] = {}          # device index -> (two pinned staging buffers, two events)
+
+
+def to_host(flat: torch.Tensor) -> np.ndarray:
+    """Device samples (float32 or int16) -> one numpy array, through two pinned staging buffers per GPU: the copy of piece
+    k + 1 from the GPU runs while piece k moves from its staging buffer into the result (a pageable copy of the whole
+    tensor is several times slower, and pinning a result-sized buffer per call costs more than it saves)."""
+    flat = flat.reshape(-1)
+    n = int(flat.numel())
+    res = np.empty(n, dtype=np.int16 if flat.dtype == torch.int16 else np.float32)
+    if n == 0:
+        return res
+    if n <= (1 << 20) or not flat.is_cuda:              # small results: not worth the staging
+        res[:] = flat.cpu().numpy()
+        return res
+    bytes_dev = flat.view(torch.uint8)
+    res_b = res.view(np.uint8)
+    nb = int(bytes_dev.numel())
+    piece = 128 << 20                                   # bytes per staging buffer
+    dev = flat.device
+    if dev.index not in _STAGE:
+        _STAGE[dev.index] = ([torch.empty(piece, dtype=torch.uint8, pin_memory=True) for _ in range(2)],
+                             [torch.cuda.Event() for _ in range(2)])
+    stage, stage_ev = _STAGE[dev.index]
+    stream = torch.cuda.current_stream(dev)
+    bounds = [(a, min(a + piece, nb)) for a in range(0, nb, piece)]
+    with torch.cuda.device(dev):
+        for k, (a, b) in enumerate(bounds[:2]):
+            stage[k][: b - a].copy_(bytes_dev[a:b], non_blocking=True)
+            stage_ev[k].record(stream)
+        for k, (a, b) in enumerate(bounds):
+            j = k & 1
+            stage_ev[j].synchronize()
+            res_b[a:b] = stage[j][: b - a].numpy()
+            if k + 2 < len(bounds):
+                a2, b2 = bounds[k + 2]
+                stage[j][: b2 - a2].copy_(bytes_dev[a2:b2], non_blocking=True)
+                stage_ev[j].record(stream)
+    return res
+
+
 class Decoder:
     """One decoder instance = one q3c context on one GPU."""
 
@@ -296,39 +337,8 @@ class Decoder:
         return [host[s:s + n] for s, n in zip(starts, lengths)], self.cfg.sample_rate
 
     def _to_host(self, flat: torch.Tensor) -> np.ndarray:
-        """Device samples (float32 or int16) -> one numpy array, through two pinned staging buffers: the copy of piece
-        k + 1 from the GPU runs while piece k moves from its staging buffer into the result (a pageable copy of the
-        whole tensor is several times slower, and pinning a result-sized buffer per call costs more than it saves)."""
-        flat = flat.reshape(-1)
-        n = int(flat.numel())
-        res = np.empty(n, dtype=np.int16 if flat.dtype == torch.int16 else np.float32)
-        if n == 0:
-            return res
-        if n <= (1 << 20):                                  # small results: not worth the staging
-            res[:] = flat.cpu().numpy()
-            return res
-        bytes_dev = flat.view(torch.uint8)
-        res_b = res.view(np.uint8)
-        nb = int(bytes_dev.numel())
-        piece = 128 << 20                                   # bytes per staging buffer
-        if self.__dict__.get("_stage") is None:
-            self._stage = [torch.empty(piece, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
-            self._stage_ev = [torch.cuda.Event() for _ in range(2)]
-        stream = torch.cuda.current_stream(self.device)
-        bounds = [(a, min(a + piece, nb)) for a in range(0, nb, piece)]
-        with torch.cuda.device(self.device):
-            for k, (a, b) in enumerate(bounds[:2]):
-                self._stage[k][: b - a].copy_(bytes_dev[a:b], non_blocking=True)
-                self._stage_ev[k].record(stream)
-            for k, (a, b) in enumerate(bounds):
-                j = k & 1
-                self._stage_ev[j].synchronize()
-                res_b[a:b] = self._stage[j][: b - a].numpy()
-                if k + 2 < len(bounds):
-                    a2, b2 = bounds[k + 2]
-                    self._stage[j][: b2 - a2].copy_(bytes_dev[a2:b2], non_blocking=True)
-                    self._stage_ev[j].record(stream)
-        return res
+        """Device samples (float32 or int16) -> one numpy array (see `to_host`)."""
+        return to_host(flat)
 
     # ------------------------------------------------------------------------------------------------
     def profile(self, on: bool, detail: bool = False) -> None:

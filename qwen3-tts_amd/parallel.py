@@ -13,6 +13,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from .decoder import to_host
+
 
 def lpt_assign(lengths: Sequence[int], world_size: int) -> List[List[int]]:
     """Longest-processing-time-first: item indices per rank, so that the summed frames per rank are balanced.
@@ -62,14 +64,19 @@ def gather_waveforms(local: Sequence[torch.Tensor], local_ids: Sequence[int], to
     flat = (torch.cat([local[j].reshape(-1).to(torch.float32) for j in order]) if order
             else torch.empty(0, dtype=torch.float32)).to(device)
 
+    out: List[Optional[np.ndarray]] = [None] * total_items
+
+    def land(r: int, buf: torch.Tensor) -> None:
+        """Rank r's flat buffer -> host (pinned double buffer on a GPU) and its utterances as views into that one array."""
+        host = to_host(buf)
+        off = 0
+        for i in per_rank_items[r]:
+            out[i] = host[off:off + length[i]]
+            off += length[i]
+
     def split(bufs: List[torch.Tensor]) -> List[np.ndarray]:
-        out: List[Optional[np.ndarray]] = [None] * total_items
         for r in range(world):
-            host = bufs[r].cpu().numpy()
-            off = 0
-            for i in per_rank_items[r]:
-                out[i] = host[off:off + length[i]].copy()
-                off += length[i]
+            land(r, bufs[r])
         return out  # type: ignore[return-value]
 
     if dst is None:
@@ -80,11 +87,20 @@ def gather_waveforms(local: Sequence[torch.Tensor], local_ids: Sequence[int], to
         dist.all_gather(bufs, mine, group=group)
         return split([b[:n] for b, n in zip(bufs, per_rank_len)])
     if rank == dst:
+        # every peer's receive is posted first (each arrives over its own link); the root's own samples go to the host while
+        # the peers are still sending, then each peer's buffer as soon as its receive has completed
         bufs = [flat if r == dst else torch.empty(per_rank_len[r], dtype=torch.float32, device=device) for r in range(world)]
-        reqs = [dist.irecv(bufs[r], src=r, group=group) for r in range(world) if r != dst and per_rank_len[r] > 0]
-        for q in reqs:
-            q.wait()
-        return split(bufs)
+        reqs = {r: dist.irecv(bufs[r], src=r, group=group) for r in range(world) if r != dst and per_rank_len[r] > 0}
+        land(dst, flat)
+        for r in range(world):
+            if r == dst:
+                continue
+            if r in reqs:
+                reqs[r].wait()
+                if bufs[r].is_cuda:
+                    torch.cuda.current_stream(bufs[r].device).synchronize()      # the receive is stream-ordered on RCCL
+            land(r, bufs[r])
+        return out  # type: ignore[return-value]
     if flat.numel() > 0:
         dist.send(flat, dst=dst, group=group)
     return None
