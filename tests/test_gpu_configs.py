@@ -337,3 +337,28 @@ def test_bf16_snake_with_large_phase():
           f"their mean sin^2 term {float(((got - x.double()) / invb)[big].mean()):.3f}")
     assert not bool(bad.any()), f"{int(bad.sum())} of {bad.numel()} outside the bound, worst {float(((got - want).abs() - bound).max()):.3e}"
     assert float(((got - x.double()) / invb)[big].mean()) > 0.3            # the sin^2 term is alive out there (mean 1/2)
+
+
+# ---- another architecture through the same code: every size is a configuration field -------------------------------------
+def test_narrow_transformer_architecture_vs_oracle():
+    """The 12 Hz tokenizer's own decoder is believed to use a narrower transformer than the sibling's default (hidden 512,
+    intermediate 1024 around a 1024-wide latent, grouped KV heads); nothing in the library is tied to the flagship sizes:
+    whole forward in fp32 against the oracle, and bf16 against the stage floors."""
+    cfg = q3.DecoderConfig(hidden_size=512, intermediate_size=1024, latent_dim=1024, num_attention_heads=8, num_key_value_heads=4,
+                           head_dim=64, num_hidden_layers=4, codebook_dim=256, rvq_out_dim=512)
+    w = q3.synthetic_weights(cfg, seed=4)
+    codes = q3.random_codes(cfg, 2, 40, seed=9)
+    taps = {}
+    ref = oracle.forward(cfg, w, codes, taps)
+    dec = Decoder(cfg, w, device="cuda:0", precision="f32")
+    rows, ref, wav = stage_report(dec, cfg, w, codes, (taps, ref))
+    print("narrow transformer fp32\n" + format_report(rows))
+    assert rows[-1][1] <= F32_MAX_ABS and rows[-1][2] >= F32_SNR_DB, format_report(rows)
+    dec.close()
+    dec16 = Decoder(cfg, w, device="cuda:0", precision="bf16")
+    rows16, _, wav16 = stage_report(dec16, cfg, w, codes, (taps, ref))
+    print("narrow transformer bf16\n" + format_report(rows16))
+    by = {r[0]: r for r in rows16}
+    for stage in ("rvq_out", "transformer_in", "transformer_out", "upsample1", "conv_in+snake"):
+        assert by[stage][2] >= BF16_STAGE_SNR_DB[stage], f"{stage}\n" + format_report(rows16)
+    assert by["wav"][2] >= BF16_STAGE_SNR_DB["wav"] - 2.0 and float(wav16.abs().max()) <= 1.0
