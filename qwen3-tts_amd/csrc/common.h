@@ -70,10 +70,14 @@ hipError_t q3_launch_rmsnorm(const void* x, const float* w, void* y, long long r
 // `hist` carried rows sit in front of each item's L rows of x (0: rows before the sequence are zero padding)
 hipError_t q3_launch_dwconv_ln(const void* x, const float* w /*[7][C], tap-major*/, const float* b, const float* lnw, const float* lnb,
                                void* y, int B, int L, int C, int k, float eps, int dtype, hipStream_t s, int hist = 0);
-// qkv holds hist + T rows per item, the last T are the queries; pos0[b] (null: 0) is the frame number of query 0
+// Keys / values of the frames before a push, one ring buffer per (slot, layer) inside the slot's state record: frame f at
+// ring row f mod hist, a row = [K (nkv*d) | V (nkv*d)] in the context's element type.
+struct Q3KvRing { const char* state; long long slot_stride, state_off; const int* slots; int capacity; };
+// qkv holds T rows per item (the queries and their keys / values); with hist > 0 the hist frames before them are read from
+// `ring`, and pos0[b] is the frame number of item b's query 0 (null: 0)
 hipError_t q3_launch_swa_attention(const void* qkv, void* out, const float* cos_t, const float* sin_t, int B, int T,
                                    int nh, int nkv, int d, int window, int dtype, hipStream_t s, int hist = 0,
-                                   const int* pos0 = nullptr, int max_pos = 1 << 30);
+                                   const int* pos0 = nullptr, int max_pos = 1 << 30, const Q3KvRing* ring = nullptr);
 
 // one carried tensor of the streaming decode; offsets and strides in bytes, all multiples of 16
 struct Q3CarryDesc {
@@ -81,11 +85,12 @@ struct Q3CarryDesc {
     long long state_off;                // offset of the carried rows inside a slot's state record
     int work_ld, col_off, row_bytes;    // row stride of the work tensor; first byte and width of the carried columns
     int rows, new_rows;                 // carried rows; rows appended by one push
-    int pad;
+    int ring;                           // 1: the state side is a ring buffer of `rows` rows (frame f at row f mod rows) that is
+                                        // only appended to: the work tensor holds the new rows alone
 };
 struct Q3StageStarts { int count; int rows[16]; };
 hipError_t q3_launch_stream_carry(const Q3CarryDesc* descs_dev, int ndesc, void* work, void* state, long long slot_stride,
-                                  const int* slots, int S, int capacity, int save, hipStream_t s);
+                                  const int* slots, int S, int capacity, int save, const int* pos0, hipStream_t s);
 hipError_t q3_launch_stream_prep(const int* slots, int S, int capacity, int* pos, int n, int max_pos, int* pos0, int* row_start,
                                  const Q3StageStarts& st, int* err_flag, hipStream_t s);
 hipError_t q3_launch_stream_reset(const int* slots, int count, int capacity, void* state, long long slot_stride, int* pos,

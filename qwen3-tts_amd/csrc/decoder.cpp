@@ -473,7 +473,10 @@ int validate_config(q3c_ctx* c) {
 // =========================================================================================================
 // a captured push: the launch sequence of one (S, n) with these exact operand addresses baked into its kernel nodes
 struct PushGraph { const void *slots, *codes, *wav, *ws; hipGraphExec_t exec; };
-struct StreamPlan { size_t ws_bytes = 0; Q3CarryDesc* descs = nullptr; int ndesc = 0; std::vector<PushGraph> graphs; };
+struct StreamPlan {
+    size_t ws_bytes = 0; Q3CarryDesc* descs = nullptr; int ndesc = 0; std::vector<PushGraph> graphs;
+    double carried_bytes = 0, appended_bytes = 0;      // per stream: rows copied in and out around a push; rows appended to rings
+};
 constexpr size_t MAX_GRAPHS_PER_PLAN = 32;
 
 }  // namespace
@@ -534,8 +537,8 @@ int stream_sequence(q3c_stream_pool* P, int S, int n, bool run, const StreamPlan
     }
     if (run) {
         LAUNCH(c, q3_launch_stream_prep(slots, S, P->capacity, P->pos, n, k.max_positions, pos0, rs_all, st, c->err_flag, s));
-        LAUNCH_B(c, s, "stream_carry", 2.0 * S * P->slot_stride,
-                 q3_launch_stream_carry(plan->descs, plan->ndesc, ws, P->state, P->slot_stride, slots, S, P->capacity, 0, s));
+        LAUNCH_B(c, s, "stream_carry", 2.0 * S * plan->carried_bytes,
+                 q3_launch_stream_carry(plan->descs, plan->ndesc, ws, P->state, P->slot_stride, slots, S, P->capacity, 0, pos0, s));
     }
 
     const int H = k.hidden_size, Lt = k.latent_dim;
@@ -569,14 +572,27 @@ int stream_sequence(q3c_stream_pool* P, int S, int n, bool run, const StreamPlan
     const size_t o_att = alloc(fr * qd * es), o_mlp = alloc(fr * k.intermediate_size * es);
     for (int l = 0; l < k.num_hidden_layers; ++l) {
         const Layer& y = c->layers[l];
-        SBuf qkv = tensor(k.sliding_window - 1, n, qd + 2 * kvd, es, qd, 2 * kvd);     // only K and V rows are carried
+        // The layer's keys and values of the window - 1 frames before this push stay where they are, in a ring buffer inside
+        // the slot's state record that the attention kernel reads directly; the new rows are appended to it after the push
+        // (the second stream_carry).  The work tensor holds the new rows only.
+        const int ring_rows = k.sliding_window - 1;
+        SBuf qkv{alloc((size_t)S * n * (qd + 2 * kvd) * es), 0, n, qd + 2 * kvd, es};
+        const long long ring_off = st_off;
+        if (ring_rows > 0) {
+            Q3CarryDesc d{};
+            d.work_off = (long long)qkv.off; d.work_bstride = (long long)n * qkv.ch * es; d.state_off = st_off;
+            d.work_ld = (int)(qkv.ch * es); d.col_off = (int)(qd * es); d.row_bytes = (int)(2 * kvd * es);
+            d.rows = ring_rows; d.new_rows = n; d.ring = 1;
+            if (descs) descs->push_back(d);
+            st_off += (long long)align_up((size_t)d.rows * d.row_bytes, 16);
+        }
         if (!run) continue;
         LAUNCH_B(c, s, "rmsnorm", 2 * fr * H * es, q3_launch_rmsnorm(x, y.ln1, nrm, (long long)fr, H, k.rms_norm_eps, dt, s));
-        GemmOpts gq; gq.segmented = true; gq.y_off = new_rows_off(qkv); gq.y_bstride = item_stride(qkv);
-        TRY(gemm(c, y.qkv, nrm, S, n, ptr(qkv), n, dt, gq, s));
+        TRY(gemm(c, y.qkv, nrm, S, n, ptr(qkv), n, dt, GemmOpts{}, s));
+        Q3KvRing ring{P->state, P->slot_stride, ring_off, slots, P->capacity};
         LAUNCH_B(c, s, "swa_attention", fr * (size_t)(2 * qd + 2 * kvd) * es,
                  q3_launch_swa_attention(ptr(qkv), ws + o_att, c->cos_t, c->sin_t, S, n, k.num_attention_heads, k.num_key_value_heads,
-                                         k.head_dim, k.sliding_window, dt, s, qkv.hist, pos0, k.max_positions));
+                                         k.head_dim, k.sliding_window, dt, s, ring_rows, pos0, k.max_positions, &ring));
         GemmOpts o1; o1.scale = y.ls_attn; o1.R = x;
         TRY(gemm(c, y.o, ws + o_att, S, n, x, n, dt, o1, s));
         LAUNCH_B(c, s, "rmsnorm", 2 * fr * H * es, q3_launch_rmsnorm(x, y.ln2, nrm, (long long)fr, H, k.rms_norm_eps, dt, s));
@@ -687,8 +703,8 @@ int stream_sequence(q3c_stream_pool* P, int S, int n, bool run, const StreamPlan
     if (run) {   // final conv to one channel, clamp fused, fp32 samples out
         GemmOpts g; g.segmented = true; g.x_hist = t_in.hist; g.act = Q3_ACT_CLAMP; g.row_start = rs_all + (size_t)(2 * nb - 1) * S;
         TRY(gemm(c, c->conv_out, ptr(t_in), S, L, wav, L, Q3_F32, g, s));
-        LAUNCH_B(c, s, "stream_carry", 2.0 * S * P->slot_stride,
-                 q3_launch_stream_carry(plan->descs, plan->ndesc, ws, P->state, P->slot_stride, slots, S, P->capacity, 1, s));
+        LAUNCH_B(c, s, "stream_carry", 2.0 * S * (plan->carried_bytes + plan->appended_bytes),
+                 q3_launch_stream_carry(plan->descs, plan->ndesc, ws, P->state, P->slot_stride, slots, S, P->capacity, 1, pos0, s));
     }
     if (ws_total) *ws_total = off;
     if (state_total) *state_total = st_off;
@@ -712,6 +728,10 @@ int stream_plan(q3c_stream_pool* P, int S, int n, StreamPlan** out, bool create)
         P->allocs.push_back(p);
         HIPCHK(c, hipMemcpy(p, descs.data(), descs.size() * sizeof(Q3CarryDesc), hipMemcpyHostToDevice));
         pl.descs = (Q3CarryDesc*)p; pl.ndesc = (int)descs.size();
+        for (const Q3CarryDesc& d : descs) {
+            if (d.ring) pl.appended_bytes += (double)std::min(d.rows, d.new_rows) * d.row_bytes;
+            else pl.carried_bytes += (double)d.rows * d.row_bytes;
+        }
         it = P->plans.emplace(std::make_pair(S, n), pl).first;
     }
     *out = &it->second;

@@ -150,9 +150,11 @@ template <typename T>
 __global__ void __launch_bounds__(256) swa_attention_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                             const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                             int Tn, int nh, int nkv, int d, int window, float scale, int hist,
-                                                            const int* __restrict__ pos0, int max_pos) {
-    // Each item's qkv buffer holds `hist` carried rows then its new rows (Tn rows in all); only the new rows are
-    // queries.  Row r is frame pos0[b] - hist + r of its stream; rows of negative frame number do not exist yet.
+                                                            const int* __restrict__ pos0, int max_pos, Q3KvRing ring) {
+    // An item has `hist` carried rows then its new rows (Tn rows in all); only the new rows are queries.  Row r is frame
+    // pos0[b] - hist + r of its stream; rows of negative frame number do not exist yet.  The new rows are rows of `qkv`
+    // (Tn - hist per item); the carried rows' keys and values are read where they live, in the slot's ring buffer inside
+    // its state record: frame f sits at ring row f mod hist, as [K (nkv*d) | V (nkv*d)].
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_att[];
     const int q0 = hist + blockIdx.x * ATT_QT;
     const int h = blockIdx.y, b = blockIdx.z;
@@ -172,7 +174,17 @@ __global__ void __launch_bounds__(256) swa_attention_kernel(const T* __restrict_
     float* Qs = Vs + (size_t)nkmax * ds;
     float* Ps = Qs + (size_t)ATT_QT * d + (size_t)wave * 4 * 64 * ATT_MAXC;     // four probability rows per wave
     const int rs = (nh + 2 * nkv) * d;             // qkv row stride
-    const T* base = qkv + (size_t)b * Tn * rs;
+    const T* base = qkv + ((long long)b * (Tn - hist) - hist) * (long long)rs;       // row r >= hist of the item is qkv row r - hist
+    const T* ring_base = nullptr;
+    if (hist > 0) {
+        const int slot = min(max(ring.slots[b], 0), ring.capacity - 1);
+        ring_base = (const T*)(ring.state + (long long)slot * ring.slot_stride + ring.state_off);
+    }
+    // keys of row `pos`: a new row, or a carried one in the ring
+    auto k_row = [&](int pos) -> const T* {
+        if (pos >= hist) return base + (size_t)pos * rs + (nh + hk) * d;
+        return ring_base + (size_t)((pos + shift) % hist) * (2 * nkv * d) + hk * d;
+    };
 
     // Staging: one thread takes EPV consecutive dimensions of both rotation halves of a row (16-byte global loads) when
     // the head size allows, else one dimension pair.  Either way an element is rotated by the same two expressions.
@@ -185,7 +197,7 @@ __global__ void __launch_bounds__(256) swa_attention_kernel(const T* __restrict_
         for (int i = tid; i < nk * gpr; i += 256) {
             const int r = i / gpr, e = (i - r * gpr) * EPV;
             const int pos = k_lo + r;
-            const T* kr = base + (size_t)pos * rs + (nh + hk) * d;
+            const T* kr = k_row(pos);
             const T* vr = kr + nkv * d;
             const int ap = min(pos + shift, max_pos - 1);
             const uint4 klo = *(const uint4*)(kr + e), khi = *(const uint4*)(kr + e + half);
@@ -220,7 +232,7 @@ __global__ void __launch_bounds__(256) swa_attention_kernel(const T* __restrict_
         for (int i = tid; i < nk * half; i += 256) {
             int r = i / half, e = i - r * half;
             int pos = k_lo + r;
-            const T* kr = base + (size_t)pos * rs + (nh + hk) * d;
+            const T* kr = k_row(pos);
             const T* vr = kr + nkv * d;
             const int ap = min(pos + shift, max_pos - 1);
             float c = cos_t[(size_t)ap * half + e], s = sin_t[(size_t)ap * half + e];
@@ -367,11 +379,25 @@ __global__ void __launch_bounds__(256) snake_kernel(const T* __restrict__ x, T* 
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) stream_carry_kernel(const Q3CarryDesc* __restrict__ descs, char* __restrict__ work,
                                                            char* __restrict__ state, long long slot_stride,
-                                                           const int* __restrict__ slots, int capacity, int save) {
+                                                           const int* __restrict__ slots, int capacity, int save,
+                                                           const int* __restrict__ pos0) {
     const Q3CarryDesc d = descs[blockIdx.x];
     const int b = blockIdx.y;
     const int slot = min(max(slots[b], 0), capacity - 1);
     const int ppr = d.row_bytes >> 4;
+    if (d.ring) {
+        // a ring buffer (keys / values of one layer): nothing to load - the attention kernel reads the ring itself; after
+        // the push the new rows (the last `rows` of them) are appended at their frame number modulo the ring size
+        if (!save) return;
+        const int first = max(0, d.new_rows - d.rows), p0 = pos0[b];
+        const char* w0 = work + d.work_off + (long long)b * d.work_bstride + d.col_off;
+        char* s0 = state + (long long)slot * slot_stride + d.state_off;
+        for (int id = threadIdx.x; id < (d.new_rows - first) * ppr; id += 256) {
+            const int row = first + id / ppr, ch = id % ppr;
+            *(uint4*)(s0 + (long long)((p0 + row) % d.rows) * d.row_bytes + ch * 16) = *(const uint4*)(w0 + (long long)row * d.work_ld + ch * 16);
+        }
+        return;
+    }
     char* w0 = work + d.work_off + (long long)b * d.work_bstride + d.col_off + (save ? (long long)d.new_rows * d.work_ld : 0);
     char* s0 = state + (long long)slot * slot_stride + d.state_off;
     for (int id = threadIdx.x; id < d.rows * ppr; id += 256) {
@@ -468,9 +494,13 @@ hipError_t q3_launch_dwconv_ln(const void* x, const float* w, const float* b, co
 }
 
 hipError_t q3_launch_swa_attention(const void* qkv, void* out, const float* cos_t, const float* sin_t, int B, int T, int nh,
-                                   int nkv, int d, int window, int dtype, hipStream_t s, int hist, const int* pos0, int max_pos) {
+                                   int nkv, int d, int window, int dtype, hipStream_t s, int hist, const int* pos0, int max_pos,
+                                   const Q3KvRing* ring_in) {
     if (B == 0 || T == 0) return hipSuccess;
     if (hist < 0 || max_pos < 1) return hipErrorInvalidValue;
+    if (hist > 0 && (!ring_in || !ring_in->state || !ring_in->slots || !pos0)) return hipErrorInvalidValue;
+    Q3KvRing ring{};
+    if (ring_in) ring = *ring_in;
     if (window < 1 || window + 3 > 64 * ATT_MAXC || (d & 3) || d > 256) return hipErrorInvalidValue;    // rows are read 16 bytes at a time
     const int nkmax = ATT_QT + window - 1;
     size_t lds = ((size_t)2 * nkmax * (d + 4) + (size_t)ATT_QT * d + 4 * 4 * 64 * ATT_MAXC) * sizeof(float);
@@ -481,11 +511,11 @@ hipError_t q3_launch_swa_attention(const void* qkv, void* out, const float* cos_
     if (dtype == Q3_BF16) {
         auto k = swa_attention_kernel<bf16>;
         if (lds > 48 * 1024 && (e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const bf16*)qkv, (bf16*)out, cos_t, sin_t, hist + T, nh, nkv, d, window, scale, hist, pos0, max_pos);
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const bf16*)qkv, (bf16*)out, cos_t, sin_t, hist + T, nh, nkv, d, window, scale, hist, pos0, max_pos, ring);
     } else {
         auto k = swa_attention_kernel<float>;
         if (lds > 48 * 1024 && (e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const float*)qkv, (float*)out, cos_t, sin_t, hist + T, nh, nkv, d, window, scale, hist, pos0, max_pos);
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const float*)qkv, (float*)out, cos_t, sin_t, hist + T, nh, nkv, d, window, scale, hist, pos0, max_pos, ring);
     }
     return hipGetLastError();
 }
@@ -540,11 +570,11 @@ hipError_t q3_launch_snake(const void* x, void* y, const float* a, const float* 
 }
 
 hipError_t q3_launch_stream_carry(const Q3CarryDesc* descs_dev, int ndesc, void* work, void* state, long long slot_stride,
-                                  const int* slots, int S, int capacity, int save, hipStream_t s) {
+                                  const int* slots, int S, int capacity, int save, const int* pos0, hipStream_t s) {
     if (ndesc == 0 || S == 0) return hipSuccess;
-    if (slot_stride & 15) return hipErrorInvalidValue;
+    if (slot_stride & 15 || !pos0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(stream_carry_kernel, dim3(ndesc, S), dim3(256), 0, s, descs_dev, (char*)work, (char*)state, slot_stride, slots,
-                       capacity, save);
+                       capacity, save, pos0);
     return hipGetLastError();
 }
 
