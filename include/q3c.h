@@ -128,7 +128,8 @@ int q3c_set_tap(q3c_ctx* ctx, int32_t stage, float* dev_buffer, size_t capacity_
  * produce exactly the samples of the un-chunked forward (sib :3672-3684) of all its frames so far: the rows each layer
  * looks back into (conv taps - the causal padding of sib :3180-3213, the previous input row of the transposed convs
  * :3216-3228, the 72-frame attention window :3267-3336, following the padding-cache pattern of mimi :73-164) are
- * carried between pushes in a per-slot state record in device memory.
+ * carried between pushes in a per-slot state record in device memory; the attention window's keys and values are per-layer
+ * ring buffers inside that record (frame f at row f mod (window - 1)), read in place and only appended to.
  *
  * A pool holds `capacity` slots.  q3c_stream_reset zeroes the given slots (a new stream starts at frame 0).
  * q3c_stream_push advances S distinct slots (ids in DEVICE memory) by n frames each in one launch sequence, whatever
