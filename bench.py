@@ -162,6 +162,35 @@ def stream_bench(args, cfg, weights, device) -> dict:
             "kernels": [{"kernel": p["kernel"], "launches": p["launches"], "ms_per_step": round(p["ms"], 3)} for p in prof[:8]]}
 
 
+def encode_bench(args, cfg, weights, device) -> dict:
+    """The quantiser's encode direction (first stage of the tokenizer's encode side): `--batch` x `--seconds` of frame
+    embeddings -> 16 codes per frame.  Algorithmic work per frame: input_proj of both groups + one squared distance to each
+    of the 2048 rows of 16 code books (3 flops per dimension: subtract, multiply, add)."""
+    frames = int(round(args.seconds * cfg.frame_rate))
+    g = torch.Generator().manual_seed(7)
+    w = dict(weights)
+    for grp in ("semantic", "acoustic"):
+        w[f"quantizer.{grp}.input_proj.weight"] = torch.randn(cfg.codebook_dim, cfg.rvq_out_dim, 1, generator=g) * cfg.rvq_out_dim ** -0.5
+    dec = Decoder(cfg, w, device=device, precision=args.precision)
+    emb = torch.randn(args.batch, frames, cfg.rvq_out_dim, generator=g).to(device)
+    for _ in range(args.warmup):
+        codes = dec.rvq_encode(emb)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        codes = dec.rvq_encode(emb)
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / args.steps
+    assert codes.shape == (args.batch, cfg.num_quantizers, frames) and int(codes.max()) < cfg.codebook_size and int(codes.min()) >= 0
+    flops = args.batch * frames * (2 * 2.0 * cfg.codebook_dim * cfg.rvq_out_dim + 3.0 * cfg.num_quantizers * cfg.codebook_size * cfg.codebook_dim)
+    return {"metric": "audio-sec encoded/sec (RVQ stage)", "value": round(args.batch * args.seconds / dt, 1), "unit": "audio-sec/sec",
+            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"RVQ encode of {args.batch} x {args.seconds:g} s of frame embeddings ({frames} frames each, width "
+                                   f"{cfg.rvq_out_dim}), {cfg.num_quantizers} code books of {cfg.codebook_size} x {cfg.codebook_dim}",
+                       "vector_tflops": round(flops / dt / 1e12, 2)}}
+
+
 def mixed_bench(args, cfg, weights, device, world, rank, distributed) -> dict:
     """BASELINE.json configs[3]: `--utterances` utterances of 2-30 s (seeded), bucketed by length, LPT-sharded over the
     ranks, decoded with no collective, waveforms gathered to rank 0 over RCCL.  Timed end to end, gather included."""
@@ -281,7 +310,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=3, help="utterances in the CPU baseline sample")
     ap.add_argument("--tiny", action="store_true", help="tiny architecture (plumbing check only; not a valid result)")
-    ap.add_argument("--workload", default="bulk", choices=["bulk", "stream", "mixed", "longform"],
+    ap.add_argument("--workload", default="bulk", choices=["bulk", "stream", "mixed", "longform", "encode"],
                     help="bulk = configs[1] (the headline); stream = configs[2]; mixed = configs[3]; longform = configs[4]")
     ap.add_argument("--utterances", type=int, default=10000)
     ap.add_argument("--streams", type=int, default=256)
@@ -312,6 +341,11 @@ def main() -> None:
         if distributed:
             raise SystemExit("the streaming workload is measured on one GPU (streams never migrate between GPUs)")
         print(json.dumps(stream_bench(args, cfg, weights, device)), flush=True)
+        return
+    if args.workload == "encode":
+        if distributed:
+            raise SystemExit("the encode workload is measured on one GPU")
+        print(json.dumps(encode_bench(args, cfg, weights, device)), flush=True)
         return
     if args.workload in ("mixed", "longform"):
         if args.workload == "longform" and args.seconds == 30.0:

@@ -113,6 +113,15 @@ int q3c_forward_static(q3c_ctx* ctx, const int64_t* codes_dev, int32_t batch, in
 int q3c_rvq_dequant_f32(q3c_ctx* ctx, const int64_t* codes_dev, int32_t batch, int32_t frames, float* sums_dev,
                         void* hip_stream);
 
+/* The ENCODE direction of the same code books (mimi :1112-1126, :1053-1068, :985-1002: the first step of the tokenizer's encode
+ * side, which the reference reaches through create_voice_clone_prompt, server.py:228-232): embeddings [B][T][in_dim] fp32 on the
+ * device -> codes [B][Q][T] int64.  Each group applies its bias-free 1x1 input_proj (loaded when the state dict has
+ * "quantizer.<group>.input_proj.weight" [codebook_dim][in_dim][1]; otherwise in_dim must equal codebook_dim), then every layer
+ * takes the nearest code-book row (smallest true squared distance, lowest index on ties) and passes the residual on; both groups
+ * encode the same embeddings.  Asynchronous on the stream. */
+int q3c_rvq_encode(q3c_ctx* ctx, const float* emb_dev, int32_t batch, int32_t frames, int32_t in_dim, int64_t* codes_dev,
+                   void* hip_stream);
+
 /* Sticky device-side error word.  Synchronises the stream; if set, clears it and returns Q3C_ERR_CODES (a code index
  * outside [0, codebook_size): stands in for the IndexError torch's embedding raises) or Q3C_ERR_INVALID_ARGUMENT
  * (streaming: bad slot id, stream longer than max_positions). */

@@ -58,6 +58,9 @@ struct q3c_ctx {
     float** tables_dev = nullptr;
     int* group_start_dev = nullptr;
     float* emb_table = nullptr;
+    void** tables_t_dev = nullptr;    // per code book a dimension-major copy [D/4][bins][4] (built when the encode weights are loaded)
+    float* rvq_in_proj = nullptr;     // [G][codebook_dim][rvq_in_dim]: the groups' input_proj (encode direction), when loaded
+    int rvq_in_dim = 0;
     GemmW rvq_proj, pre_conv, in_proj, out_proj;
     // transformer
     std::vector<Layer> layers;
@@ -807,6 +810,7 @@ int q3c_finalize(q3c_ctx* c) {
         std::vector<int> gs = {0, ns};
         if (c->G == 2) gs.push_back(k.num_quantizers);
         std::vector<float> proj((size_t)k.rvq_out_dim * c->G * D);
+        std::vector<void*> tables_t;
         for (int g = 0; g < c->G; ++g) {
             const std::string gn = g == 0 ? "semantic" : "acoustic";
             for (int i = 0; i < gs[g + 1] - gs[g]; ++i) {
@@ -820,6 +824,13 @@ int q3c_finalize(q3c_ctx* c) {
                 }
                 float* tp; TRY(upload_f32(c, tab, &tp));
                 c->tables.push_back(tp);
+                {   // the encode direction reads the table by dimension: [D/4][bins][4]
+                    std::vector<float> tt(tab.size());
+                    for (int r = 0; r < k.codebook_size; ++r)
+                        for (int d = 0; d < D; ++d) tt[((size_t)(d >> 2) * k.codebook_size + r) * 4 + (d & 3)] = tab[(size_t)r * D + d];
+                    float* tpt; TRY(upload_f32(c, tt, &tpt));
+                    tables_t.push_back(tpt);
+                }
             }
             GETW(op, "quantizer." + gn + ".output_proj.weight", k.rvq_out_dim, D, 1);
             for (int n = 0; n < k.rvq_out_dim; ++n)
@@ -828,9 +839,26 @@ int q3c_finalize(q3c_ctx* c) {
         TRY(dev_alloc(c, c->tables.size() * sizeof(float*), &p));
         c->tables_dev = (float**)p;
         HIPCHK(c, hipMemcpy(p, c->tables.data(), c->tables.size() * sizeof(float*), hipMemcpyHostToDevice));
+        TRY(dev_alloc(c, tables_t.size() * sizeof(void*), &p));
+        c->tables_t_dev = (void**)p;
+        HIPCHK(c, hipMemcpy(p, tables_t.data(), tables_t.size() * sizeof(void*), hipMemcpyHostToDevice));
         TRY(dev_alloc(c, gs.size() * sizeof(int), &p));
         c->group_start_dev = (int*)p;
         HIPCHK(c, hipMemcpy(p, gs.data(), gs.size() * sizeof(int), hipMemcpyHostToDevice));
+        // encode direction (optional): the groups' bias-free 1x1 input_proj [codebook_dim][in_dim][1], all or none
+        if (c->staged.count("quantizer.semantic.input_proj.weight")) {
+            const HostTensor& first = c->staged["quantizer.semantic.input_proj.weight"];
+            if (first.shape.size() != 3 || first.shape[0] != D || first.shape[2] != 1 || first.shape[1] < 1)
+                return fail(c, Q3C_ERR_WEIGHT, "quantizer.semantic.input_proj.weight must be [codebook_dim][in_dim][1]");
+            const int in_dim = (int)first.shape[1];
+            std::vector<float> ip((size_t)c->G * D * in_dim);
+            for (int g = 0; g < c->G; ++g) {
+                GETW(w_in, std::string("quantizer.") + (g == 0 ? "semantic" : "acoustic") + ".input_proj.weight", D, in_dim, 1);
+                std::memcpy(&ip[(size_t)g * D * in_dim], w_in->data.data(), (size_t)D * in_dim * sizeof(float));
+            }
+            TRY(upload_f32(c, ip, &c->rvq_in_proj));
+            c->rvq_in_dim = in_dim;
+        }
         // both groups' 1x1 projections as ONE contraction over the concatenated sums: always fp32 operands
         c->rvq_proj.taps = 1; c->rvq_proj.N = k.rvq_out_dim; c->rvq_proj.K = c->G * D; c->rvq_proj.in_dtype = Q3_F32;
         TRY(upload_typed(c, proj, Q3_F32, &c->rvq_proj.w));
@@ -988,6 +1016,21 @@ int q3c_rvq_dequant_f32(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, 
 }
 
 static int forward_impl(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, float* wav, void* ws, size_t ws_bytes, void* stream);
+
+int q3c_rvq_encode(q3c_ctx* c, const float* emb, int32_t B, int32_t T, int32_t in_dim, int64_t* codes, void* stream) {
+    if (!c) return Q3C_ERR_INVALID_ARGUMENT;
+    if (!c->finalized) return fail(c, Q3C_ERR_STATE, "q3c_finalize has not run");
+    if (c->cfg.frontend != Q3C_FRONTEND_SPLIT_RVQ) return fail(c, Q3C_ERR_STATE, "context has no RVQ front end");
+    if (!emb || !codes || B < 1 || T < 1) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "q3c_rvq_encode: bad argument");
+    const int want = c->rvq_in_proj ? c->rvq_in_dim : c->cfg.codebook_dim;
+    if (in_dim != want)
+        return fail(c, Q3C_ERR_INVALID_ARGUMENT, "q3c_rvq_encode: embeddings have " + std::to_string(in_dim) + " channels, the quantizer takes " +
+                                                     std::to_string(want) + (c->rvq_in_proj ? " (its input_proj)" : " (no input_proj was loaded)"));
+    LAUNCH(c, q3_launch_rvq_encode(emb, B, T, in_dim, c->cfg.num_quantizers, c->cfg.codebook_size, c->cfg.codebook_dim, c->tables_dev,
+                                   (const void* const*)c->tables_t_dev, c->group_start_dev, c->G, c->rvq_in_proj, (long long*)codes,
+                                   (hipStream_t)stream));
+    return 0;
+}
 
 int q3c_forward(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, float* wav, void* ws, size_t ws_bytes, void* stream) {
     if (!c) return Q3C_ERR_INVALID_ARGUMENT;

@@ -36,6 +36,110 @@ __global__ void __launch_bounds__(256) rvq_gather_sum_kernel(const long long* __
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// RVQ encode (nearest code-book row per layer, residual passed on): the encode direction of the same code books.
+// One block takes RVQ_FT frames through every layer of every group: the frames' residuals live in LDS, thread t scores
+// code rows t, t + 256, ... against all of them (true squared distances, one fma chain per (frame, code) in dimension
+// order; the rows come from a dimension-major copy of the table, so a wave's loads are contiguous), the block reduces to the smallest distance with the lowest index
+// on ties (what argmin returns), and the winners' rows are subtracted from the residuals.
+// ------------------------------------------------------------------------------------------------
+constexpr int RVQ_FT = 8;
+
+__global__ void __launch_bounds__(256) rvq_encode_kernel(const float* __restrict__ emb, long long frames, int T, int in_dim, int Q,
+                                                         int bins, int D, const float* const* __restrict__ tables,
+                                                         const float4* const* __restrict__ tables_t /*[Q] x [D/4][bins] float4*/,
+                                                         const int* __restrict__ group_start, int G,
+                                                         const float* __restrict__ in_proj /*[G][D][in_dim] or null*/,
+                                                         long long* __restrict__ codes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_rvq[];
+    float* E = (float*)smem_rvq;                           // [RVQ_FT][in_dim]  the frames' embeddings
+    float* R = E + (size_t)RVQ_FT * in_dim;                // [RVQ_FT][D]       residuals of the current group
+    float* bd = R + (size_t)RVQ_FT * D;                    // [4 waves][RVQ_FT] per-wave best distance
+    int* bi = (int*)(bd + 4 * RVQ_FT);                     // [4 waves][RVQ_FT] ... and its index
+    int* win = bi + 4 * RVQ_FT;                            // [RVQ_FT]          the block's winner
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long f0 = (long long)blockIdx.x * RVQ_FT;
+    const int nf = (int)min((long long)RVQ_FT, frames - f0);
+    for (int i = tid; i < RVQ_FT * in_dim; i += 256) {
+        const int f = i / in_dim, e = i - f * in_dim;
+        E[i] = f < nf ? emb[(f0 + f) * in_dim + e] : 0.f;
+    }
+    __syncthreads();
+    for (int g = 0; g < G; ++g) {
+        // residual <- input_proj_g(embedding), or the embedding itself
+        for (int i = tid; i < RVQ_FT * D; i += 256) {
+            const int f = i / D, j = i - f * D;
+            float a;
+            if (in_proj) {
+                const float* wr = in_proj + ((size_t)g * D + j) * in_dim;
+                a = 0.f;
+                for (int e = 0; e < in_dim; ++e) a = fmaf(wr[e], E[f * in_dim + e], a);
+            } else {
+                a = E[f * in_dim + j];
+            }
+            R[i] = a;
+        }
+        __syncthreads();
+        for (int q = group_start[g]; q < group_start[g + 1]; ++q) {
+            const float* tab = tables[q];
+            float best[RVQ_FT];
+            int besti[RVQ_FT];
+#pragma unroll
+            for (int f = 0; f < RVQ_FT; ++f) { best[f] = INFINITY; besti[f] = 0x7fffffff; }
+            const float4* tt = tables_t[q];                // dimension-major copy: consecutive codes are consecutive float4s
+            for (int c = tid; c < bins; c += 256) {
+                float acc[RVQ_FT];
+#pragma unroll
+                for (int f = 0; f < RVQ_FT; ++f) acc[f] = 0.f;
+                for (int d0 = 0; d0 < D; d0 += 4) {
+                    const float4 e4 = tt[(size_t)(d0 >> 2) * bins + c];
+#pragma unroll
+                    for (int f = 0; f < RVQ_FT; ++f) {
+                        const float4 r4 = *(const float4*)(R + f * D + d0);
+                        const float x = r4.x - e4.x, y = r4.y - e4.y, z = r4.z - e4.z, w = r4.w - e4.w;
+                        acc[f] = fmaf(w, w, fmaf(z, z, fmaf(y, y, fmaf(x, x, acc[f]))));
+                    }
+                }
+#pragma unroll
+                for (int f = 0; f < RVQ_FT; ++f)
+                    if (acc[f] < best[f]) { best[f] = acc[f]; besti[f] = c; }       // codes ascend: the first minimum stays
+            }
+#pragma unroll
+            for (int f = 0; f < RVQ_FT; ++f) {
+                float v = best[f];
+                int ix = besti[f];
+                for (int off = 32; off > 0; off >>= 1) {
+                    const float ov = __shfl_xor(v, off);
+                    const int oi = __shfl_xor(ix, off);
+                    if (ov < v || (ov == v && oi < ix)) { v = ov; ix = oi; }
+                }
+                if (lane == 0) { bd[wave * RVQ_FT + f] = v; bi[wave * RVQ_FT + f] = ix; }
+            }
+            __syncthreads();
+            if (tid < RVQ_FT) {
+                float v = bd[tid];
+                int ix = bi[tid];
+                for (int w2 = 1; w2 < 4; ++w2) {
+                    const float ov = bd[w2 * RVQ_FT + tid];
+                    const int oi = bi[w2 * RVQ_FT + tid];
+                    if (ov < v || (ov == v && oi < ix)) { v = ov; ix = oi; }
+                }
+                win[tid] = ix;
+                if (tid < nf) {
+                    const long long fr = f0 + tid, b = fr / T, t = fr - b * T;
+                    codes[(b * Q + q) * T + t] = ix;
+                }
+            }
+            __syncthreads();
+            for (int i = tid; i < RVQ_FT * D; i += 256) {
+                const int f = i / D, j = i - f * D;
+                R[i] = R[i] - tab[(size_t)win[f] * D + j];
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // Embedding(Q*bins, H)(codes + q*bins).mean(1): ordered sum then divide by Q.
 template <typename T>
 __global__ void __launch_bounds__(256) mean_embedding_kernel(const long long* __restrict__ codes, int B, int Q, int Tn, int bins,
@@ -554,6 +658,23 @@ hipError_t q3_launch_rvq_gather_sum(const long long* codes, int B, int Q, int T,
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(rvq_gather_sum_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, codes, B, Q, T, bins, D, tables_dev,
                        group_start_dev, G, out, err_flag);
+    return hipGetLastError();
+}
+
+hipError_t q3_launch_rvq_encode(const float* emb, int B, int T, int in_dim, int Q, int bins, int D, const float* const* tables_dev,
+                                const void* const* tables_t_dev, const int* group_start_dev, int G, const float* in_proj_dev,
+                                long long* codes, hipStream_t s) {
+    const long long frames = (long long)B * T;
+    if (frames == 0) return hipSuccess;
+    if ((D & 3) || D < 4 || in_dim < 1 || (!in_proj_dev && in_dim != D)) return hipErrorInvalidValue;
+    const size_t lds = ((size_t)RVQ_FT * (in_dim + D) + 4 * RVQ_FT) * sizeof(float) + (4 * RVQ_FT + RVQ_FT) * sizeof(int);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    hipError_t e;
+    if (lds > 48 * 1024 && (e = hipFuncSetAttribute((const void*)rvq_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+    const long long blocks = (frames + RVQ_FT - 1) / RVQ_FT;
+    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rvq_encode_kernel, dim3((unsigned)blocks), dim3(256), lds, s, emb, frames, T, in_dim, Q, bins, D, tables_dev,
+                       (const float4* const*)tables_t_dev, group_start_dev, G, in_proj_dev, codes);
     return hipGetLastError();
 }
 

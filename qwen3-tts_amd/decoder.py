@@ -261,6 +261,20 @@ class Decoder:
             self._check(self._lib.q3c_check_errors(self._ctx, self._stream()))
         return out
 
+    def rvq_encode(self, embeddings: torch.Tensor) -> torch.Tensor:
+        """The quantiser's encode direction: embeddings [B, T, D_in] (fp32, channels-last) -> codes [B, Q, T] int64 on the
+        device.  D_in is the input width of the groups' `input_proj` when the weights held one, else the code-book row
+        width."""
+        x = embeddings.to(self.device, torch.float32).contiguous()
+        if x.dim() != 3:
+            raise ValueError(f"Expected [B, T, D] embeddings, got {tuple(x.shape)}")
+        B, T, Din = x.shape
+        codes = torch.empty((B, self.cfg.num_quantizers, T), dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self._lib.q3c_rvq_encode(self._ctx, C.c_void_p(x.data_ptr()), B, T, Din, C.c_void_p(codes.data_ptr()),
+                                                 self._stream()))
+        return codes
+
     # ------------------------------------------------------------------------------------------------
     def _normalize_items(self, encoded: CodesLike) -> List[torch.Tensor]:
         """Accepts a [T, Q] / [Q, T] matrix, a [B, T, Q] / [B, Q, T] tensor, {"audio_codes": ...}, or a list of

@@ -201,6 +201,7 @@ def install_decoder(model: Any, precision: str = "bf16", device: Optional[Any] =
     if decoder_factory is None:
         from .decoder import Decoder as decoder_factory          # noqa: N813  (needs the built library)
     names = {n for n, *_ in param_specs(cfg)}
+    names |= {k for k in w if k.startswith("quantizer.") and k.endswith(".input_proj.weight")}      # encode direction, optional
     new = decoder_factory(cfg, {k: v for k, v in w.items() if k in names}, device=device, precision=precision, **decoder_kwargs)
     if not hasattr(tok, "reference_decode"):
         tok.reference_decode = tok.decode

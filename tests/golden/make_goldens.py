@@ -92,6 +92,41 @@ def make_rvq():
              codes=codes, group_sums=sums, out=want.permute(0, 2, 1).contiguous())
 
 
+def make_rvq_encode():
+    """The quantiser's ENCODE direction: mimi's split RVQ `encode` on seeded embeddings (its input_proj random, its code
+    books the synthetic ones): expected codes, and the oracle must reproduce them exactly."""
+    g = torch.Generator().manual_seed(31)
+    for tag, kw, B, T in (("rvq_encode_tiny", dict(codebook_size=32, num_quantizers=4, num_semantic_quantizers=1, codebook_dim=8, rvq_out_dim=16), 2, 41),
+                          ("rvq_encode_q16", dict(codebook_size=256, num_quantizers=16, num_semantic_quantizers=1, codebook_dim=16, rvq_out_dim=32), 2, 29)):
+        cfg = q3.tiny_config(**kw)
+        w = q3.synthetic_weights(cfg, seed=13)
+        mc = MimiConfig(codebook_size=cfg.codebook_size, codebook_dim=cfg.codebook_dim,
+                        vector_quantization_hidden_dimension=cfg.codebook_dim, hidden_size=cfg.rvq_out_dim,
+                        num_quantizers=cfg.num_quantizers, num_semantic_quantizers=cfg.num_semantic_quantizers)
+        m = mimi.MimiSplitResidualVectorQuantizer(mc).eval()
+        sd, extra = {}, {}
+        for grp, attr in (("semantic", "semantic_residual_vector_quantizer"), ("acoustic", "acoustic_residual_vector_quantizer")):
+            n = cfg.num_semantic_quantizers if grp == "semantic" else cfg.num_quantizers - cfg.num_semantic_quantizers
+            for i in range(n):
+                sd[f"{attr}.layers.{i}.codebook.embed_sum"] = w[f"quantizer.{grp}.layers.{i}.embed_sum"]
+                sd[f"{attr}.layers.{i}.codebook.cluster_usage"] = w[f"quantizer.{grp}.layers.{i}.cluster_usage"]
+                sd[f"{attr}.layers.{i}.codebook.initialized"] = torch.tensor([1.0])
+            sd[f"{attr}.output_proj.weight"] = w[f"quantizer.{grp}.output_proj.weight"]
+            ip = torch.randn(cfg.codebook_dim, cfg.rvq_out_dim, 1, generator=g) * (cfg.rvq_out_dim ** -0.5) * 3.0
+            sd[f"{attr}.input_proj.weight"] = ip
+            extra[f"quantizer.{grp}.input_proj.weight"] = ip
+        m.load_state_dict(sd, strict=True)
+        emb = torch.randn(B, cfg.rvq_out_dim, T, generator=g) * 2.0
+        with torch.no_grad():
+            want = m.encode(emb).permute(1, 0, 2).contiguous()            # [K, B, T] -> [B, K, T]
+        got = oracle.rvq_encode(cfg, {**w, **extra}, emb)
+        assert torch.equal(got, want), "oracle rvq_encode differs from mimi"
+        assert want.shape == (B, cfg.num_quantizers, T) and int(want.max()) < cfg.codebook_size
+        assert len(torch.unique(want)) > cfg.codebook_size // 4                # the code books are really used
+        save(tag, dict(config=cfg.to_dict(), weight_seed=13, weight_abs_sum=wsum(w)),
+             embeddings=emb, codes=want, **{k.replace(".", "__"): v for k, v in extra.items()})
+
+
 # ---------------------------------------------------------------------------------------------
 def make_primitives():
     g = torch.Generator().manual_seed(21)
@@ -255,6 +290,7 @@ def make_transformer_parts():
 
 if __name__ == "__main__":
     make_rvq()
+    make_rvq_encode()
     make_primitives()
     make_decoder()
     make_transformer_parts()

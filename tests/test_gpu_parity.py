@@ -87,6 +87,80 @@ def test_rvq_negative_zero_and_bad_code():
     dec.rvq_dequant(torch.zeros_like(codes))                                       # flag was cleared
 
 
+# ---- RVQ encode (the encode direction of the same code books) --------------------------------------------
+def _greedy_check(cfg, w, emb, codes, group, lo, hi, tol=2e-6):
+    """Every chosen row must be a nearest row of its layer's residual, judged in float64 along the kernel's OWN choices:
+    a different pick from the reference's is legitimate only where two rows are equally near to fp32 rounding."""
+    key = f"quantizer.{group}.input_proj.weight"
+    x = emb.double()
+    if key in w:
+        x = torch.einsum("btd,jd->btj", x, w[key][:, :, 0].double())
+    res = x.clone()
+    worst = 0.0
+    for i in range(hi - lo):
+        tab = oracle.codebook_table(w[f"quantizer.{group}.layers.{i}.embed_sum"], w[f"quantizer.{group}.layers.{i}.cluster_usage"], cfg.rvq_eps).double()
+        d = torch.cdist(res.reshape(-1, res.shape[-1])[None], tab[None])[0].pow(2)          # [frames, bins]
+        pick = codes[:, lo + i].reshape(-1)
+        dp = d.gather(1, pick[:, None])[:, 0]
+        gap = (dp - d.min(1).values) / d.min(1).values.clamp(min=1e-30)
+        worst = max(worst, float(gap.max()))
+        assert float(gap.max()) <= tol, (group, i, float(gap.max()))
+        res = res - tab[codes[:, lo + i]]
+    return worst
+
+
+@pytest.mark.parametrize("name", ["rvq_encode_tiny", "rvq_encode_q16"])
+def test_rvq_encode_vs_golden(golden, name):
+    """Codes from the kernel against mimi's `encode` outputs: equal, except where two code-book rows are equally near to
+    fp32 rounding (the reference measures distances through a matrix product, the kernel as true squared distances); any
+    such pick is checked to be a nearest row in float64."""
+    meta, a = golden(name)
+    cfg, w = _weights(meta)
+    w = {**w, **{k.replace("__", "."): torch.from_numpy(v) for k, v in a.items() if k.startswith("quantizer__")}}
+    dec = _decoder(cfg, w, "f32")
+    emb = torch.from_numpy(a["embeddings"]).permute(0, 2, 1).contiguous()                # [B, T, D_in]
+    got = dec.rvq_encode(emb).cpu()
+    want = torch.from_numpy(a["codes"])
+    assert got.shape == want.shape and got.dtype == torch.int64
+    same = float((got == want).float().mean())
+    print(f"{name}: {same:.4%} of the codes equal the sibling's")
+    ns = cfg.num_semantic_quantizers
+    _greedy_check(cfg, w, emb, got, "semantic", 0, ns)
+    _greedy_check(cfg, w, emb, got, "acoustic", ns, cfg.num_quantizers)
+    # a frame whose codes differ somewhere differs from its first near-tie on (the residuals part ways): count frames
+    frames_same = float((got == want).all(dim=1).float().mean())
+    assert frames_same >= 0.97, frames_same
+    with pytest.raises(RuntimeError, match="channels"):
+        dec.rvq_encode(torch.zeros(1, 3, cfg.codebook_dim + 1))                          # wrong width
+
+
+def test_rvq_encode_full_size_round_trip():
+    """Full-size code books (16 x 2048 x 256, input width 512), 2 x 300 frames: the kernel's codes are a valid greedy
+    quantisation (float64 check per layer), agree with the oracle's wherever no near-tie intervenes, and decoding them
+    with the gather-and-sum kernel approaches the projected embedding monotonically."""
+    cfg = q3.tiny_config(codebook_size=2048, num_quantizers=16, codebook_dim=256, rvq_out_dim=512)
+    w = q3.synthetic_weights(cfg, seed=3)
+    g = torch.Generator().manual_seed(5)
+    for grp in ("semantic", "acoustic"):
+        w[f"quantizer.{grp}.input_proj.weight"] = torch.randn(256, 512, 1, generator=g) * (512 ** -0.5) * 3.0
+    dec = _decoder(cfg, w, "f32")
+    emb = torch.randn(2, 300, 512, generator=g) * 2.0
+    got = dec.rvq_encode(emb).cpu()
+    want = oracle.rvq_encode(cfg, w, emb.permute(0, 2, 1))
+    same = float((got == want).all(dim=1).float().mean())
+    print(f"full size: {same:.4%} of the frames have all 16 codes equal to the oracle's")
+    assert same >= 0.97
+    _greedy_check(cfg, w, emb, got, "semantic", 0, 1)
+    _greedy_check(cfg, w, emb, got, "acoustic", 1, 16)
+    sums = dec.rvq_dequant(got.cuda()).cpu()                                              # [B, T, G, D]
+    x = torch.einsum("btd,jd->btj", emb, w["quantizer.acoustic.input_proj.weight"][:, :, 0])
+    full = float((x - sums[:, :, 1]).norm() / x.norm())
+    first = float((x - oracle.codebook_table(w["quantizer.acoustic.layers.0.embed_sum"], w["quantizer.acoustic.layers.0.cluster_usage"],
+                                             cfg.rvq_eps)[got[:, 1]]).norm() / x.norm())
+    print(f"relative residual after 1 layer {first:.3f}, after 15 layers {full:.3f}")
+    assert full < first < 1.0
+
+
 # ---- single operators against the sibling fixtures ------------------------------------------------------
 @pytest.mark.parametrize("precision,atol", [("f32", 2e-5), ("bf16", 6e-2)])
 def test_operators_vs_golden(golden, precision, atol):

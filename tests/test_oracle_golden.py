@@ -27,6 +27,32 @@ def test_rvq_bit_exact(golden, name):
     np.testing.assert_allclose(out.numpy(), a["out"], atol=1e-5, rtol=1e-5)
 
 
+def _encode_weights(cfg, w, a):
+    extra = {k.replace("__", "."): torch.from_numpy(v) for k, v in a.items() if k.startswith("quantizer__")}
+    assert set(extra) == {"quantizer.semantic.input_proj.weight", "quantizer.acoustic.input_proj.weight"}
+    return {**w, **extra}
+
+
+@pytest.mark.parametrize("name", ["rvq_encode_tiny", "rvq_encode_q16"])
+def test_rvq_encode_equals_the_sibling(golden, name):
+    """The encode direction (input_proj, nearest row per layer, residual passed on; both groups on the same embeddings)
+    against mimi's split RVQ `encode`: identical codes."""
+    meta, a = golden(name)
+    cfg, w = _weights(meta)
+    got = oracle.rvq_encode(cfg, _encode_weights(cfg, w, a), torch.from_numpy(a["embeddings"]))
+    assert got.dtype == torch.int64 and torch.equal(got, torch.from_numpy(a["codes"]))
+    # the codes are a greedy residual quantisation: decoding them approaches the projected embedding, layer by layer
+    ws = _encode_weights(cfg, w, a)
+    x = torch.nn.functional.conv1d(torch.from_numpy(a["embeddings"]), ws["quantizer.acoustic.input_proj.weight"]).permute(0, 2, 1)
+    ns = cfg.num_semantic_quantizers
+    res, norms = x.clone(), []
+    for i in range(cfg.num_quantizers - ns):
+        tab = oracle.codebook_table(w[f"quantizer.acoustic.layers.{i}.embed_sum"], w[f"quantizer.acoustic.layers.{i}.cluster_usage"], cfg.rvq_eps)
+        res = res - tab[got[:, ns + i]]
+        norms.append(float(res.norm()))
+    assert all(b <= a_ + 1e-6 for a_, b in zip([float(x.norm())] + norms[:-1], norms))
+
+
 def test_rvq_negative_zero_start():
     """The accumulator starts at +0.0, so a single row of -0.0 dequantises to +0.0."""
     table = torch.tensor([[-0.0, 1.0]], dtype=torch.float32)
