@@ -10,7 +10,10 @@ hipError_t q3_convgemm_f32_bf16(const ConvGemmArgs& a, hipStream_t s);
 hipError_t q3_convgemm_bf16_f32(const ConvGemmArgs& a, hipStream_t s);
 
 // the h tile of the fused residual unit (256 rows x N channels of the operand type) must fit LDS beside the weight buffers
-int q3_convgemm_fusable(int N, int dtype) { return N <= (dtype == Q3_BF16 ? 192 : 96); }
+// 384 channels fit one launch too (shape "resunit 128x384"), but measured equal to the two-launch unit in bulk (22.1 ms
+// against 14.9 + 6.4 ms per 64 x 300 frames: eight waves at one block per CU run the contraction at 0.77 of the
+// unfused 7-tap conv's rate) and 2 % slower for frame-rate pushes, so it stays behind tuning bit 64.
+int q3_convgemm_fusable(int N, int dtype) { return N <= (dtype == Q3_BF16 ? ((q3_convgemm_tuning & 64) ? 384 : 192) : 96); }
 void q3_convgemm_set_tuning(int bits) { q3_convgemm_tuning = bits; }
 extern "C" void q3c_debug_set_tuning(int bits) { q3_convgemm_tuning = bits; }   // measurement aid (tools/): not part of include/q3c.h
 // measurement aid (tools/timeline.py): phase timestamps of every 64th workgroup of the launches that follow
@@ -21,7 +24,7 @@ extern "C" void q3c_debug_set_timeline(long long* dev_buffer, int slots) { q3_ti
 const char* q3_convgemm_variant(const ConvGemmArgs& a, int in_dtype, int out_dtype) {
     static const char* shapes[SH_COUNT] = {"256x96,k64B,4w", "256x128,k128B,8w", "128x128,k128B,4w", "128x128,k64B,4w", "256x32,k64B,4w",
                                            "resunit 256x192,k64B,8w", "resunit 256x96,k64B,4w", "resunit 256x32,k64B,4w",
-                                           "256x128,k64B,8w", "resunit 128x192,k64B,4w"};
+                                           "256x128,k64B,8w", "resunit 128x192,k64B,4w", "resunit 128x384,k64B,8w"};
     static const char* types[4] = {"f32,f32", "bf16,bf16", "f32,bf16", "bf16,f32"};
     static char names[4][SH_COUNT][64];
     const int t = (in_dtype == Q3_F32 && out_dtype == Q3_F32) ? 0 : (in_dtype == Q3_BF16 ? (out_dtype == Q3_BF16 ? 1 : 3) : 2);

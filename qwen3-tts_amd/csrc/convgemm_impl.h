@@ -148,7 +148,18 @@ convgemm_kernel(const ConvGemmArgs p) {
         // slowest over the WHOLE grid (tile_order 0), so the run walks down the rows of one or two N tiles.  Layers with
         // small weights: N tile fastest (1), so the blocks sharing an input tile run side by side and it comes from
         // HBM once.
-        if ((p.tile_order == 0) != ((p.debug & 32) != 0)) {
+        if (p.tile_order == 2 && !(p.debug & 32)) {
+            // N tiles in PAIRS: the run walks down the rows with the two tiles of a row side by side, so the weights of two
+            // N tiles stay in L2 (as with order 0) while each input row tile comes from HBM once per pair, not once per tile
+            const int m_tiles = gridDim.x / n_tiles, rows_all = m_tiles * gridDim.y;
+            const int full_pairs = n_tiles >> 1, in_pairs = full_pairs * 2 * rows_all;
+            int nt, rest;
+            if (id < in_pairs) { const int pr = id / (2 * rows_all), r = id - pr * 2 * rows_all; nt = pr * 2 + (r & 1); rest = r >> 1; }
+            else { nt = n_tiles - 1; rest = id - in_pairs; }
+            b = rest / m_tiles;
+            n0 = nt * BN;
+            m0 = (rest - b * m_tiles) * BM;
+        } else if ((p.tile_order == 0) != ((p.debug & 32) != 0)) {
             const int m_tiles = gridDim.x / n_tiles, per_n = m_tiles * gridDim.y;
             const int nt = id / per_n, rest = id - nt * per_n;
             b = rest / m_tiles;
@@ -1162,7 +1173,13 @@ hipError_t launch_cfg(const ConvGemmArgs& a_in, hipStream_t s) {
                   a.ldy % 8 || a.ldr % 8 || a.N % 8))
         return hipErrorInvalidValue;
     const size_t xbuf = (size_t)((HR * CPR + 63) / 64) * 1024, wbuf = round_kb((size_t)BN * BKB), wring = 3 * wbuf + 1024;   // + a spare KiB for padding DMAs
-    a.tile_order = (long long)a.taps * a.N * a.K * (long long)sizeof(TA) <= (2LL << 20) ? 1 : 0;
+    {
+        const long long wbytes = (long long)a.taps * a.N * a.K * (long long)sizeof(TA);
+        // weights that fit an XCD's L2 beside the streams (<= 2.5 MB): N tile fastest, the input comes from HBM once; larger
+        // ones: N tiles in pairs (two tiles' weights resident, the input once per pair; measured against N tile slowest:
+        // transposed conv 768 -> 5 x 384 +8.5 %, k = 7 conv of 768 channels +0.8 %).  Tuning bit 16 = N tile slowest.
+        a.tile_order = wbytes <= (5LL << 19) ? 1 : ((::q3_convgemm_tuning & 16) ? 0 : 2);
+    }
     a.nxb = (a.taps <= 3 && round_kb(3 * xbuf) + wring <= 160 * 1024) ? 3 : 2;
     // a third input buffer is not worth a CU's second block
     if (a.nxb == 3 && a.taps > 1 && round_kb(3 * xbuf) + wring > 80 * 1024 && round_kb(2 * xbuf) + wring <= 80 * 1024) a.nxb = 2;
@@ -1188,7 +1205,7 @@ hipError_t launch_cfg(const ConvGemmArgs& a_in, hipStream_t s) {
 
 // tile shapes (rows x columns, K-row bytes, waves)
 enum { SH_256x96 = 0, SH_256x128_K128, SH_128x128_K128, SH_128x128_K64, SH_256x32, SH_F_256x192, SH_F_256x96, SH_F_256x32,
-       SH_256x128_K64, SH_F_128x192, SH_COUNT };
+       SH_256x128_K64, SH_F_128x192, SH_F_128x384, SH_COUNT };
 
 int pick_shape(const ConvGemmArgs& a, size_t elem) {
     if (a.W2) {                                   // fused residual unit: one N tile must hold every channel
@@ -1197,6 +1214,9 @@ int pick_shape(const ConvGemmArgs& a, size_t elem) {
         // 128-row tiles on four waves keep the unit's LDS under 80 KB: two independent blocks per CU, one's h tile and
         // epilogue under the other's MFMAs, against one 8-wave block in lockstep
         if (a.N <= 192) return (elem == 2 && !(q3_convgemm_tuning & 4)) ? SH_F_128x192 : SH_F_256x192;
+        // 384 channels (bf16): 128 rows x 384 columns on eight waves, one block per CU; the whole first-contraction weight
+        // (2 MB) is re-streamed from L2 per 128 rows, which the matrix pipe's time per tile still covers
+        if (a.N <= 384 && elem == 2) return SH_F_128x384;
         return -1;
     }
     const bool wide_k = ((size_t)a.K * elem) % 128 == 0;
@@ -1230,6 +1250,9 @@ hipError_t launch_typed(const ConvGemmArgs& a, hipStream_t s) {
         switch (pick_shape(a, sizeof(TA))) {
             case SH_F_256x192: return launch_cfg<TA, TO, 4, 2, 2, 3, 64, true>(a, s);    // 2x3 tiles per wave: 5 LDS reads per 6 MFMAs (1x6: 7)
             case SH_F_128x192: return launch_cfg<TA, TO, 2, 2, 2, 3, 64, true>(a, s);
+            case SH_F_128x384:
+                if constexpr (sizeof(TA) == 2) return launch_cfg<TA, TO, 2, 4, 2, 3, 64, true>(a, s);
+                break;
             case SH_F_256x96: return launch_cfg<TA, TO, 4, 1, 2, 3, 64, true>(a, s);
             case SH_F_256x32: return launch_cfg<TA, TO, 4, 1, 2, 1, 64, true>(a, s);
             default: break;

@@ -429,3 +429,28 @@ def test_operators_at_production_tile_shapes(precision):
     check("linear1024", D.causal_conv1d(x.permute(0, 2, 1).contiguous().cuda(), w, b, 1, precision), oracle.causal_conv1d(x, w, b, 1, 1))
     print(f"production shapes {precision}: max|err| / max|y| " + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
 
+
+def test_one_launch_unit_at_384_channels_matches_two_launches():
+    """The opt-in one-launch residual unit for 384 channels (tile shape 128 x 384, switched on by the library's
+    measurement knob) against the oracle and against the default two-launch unit on the same input."""
+    from qwen3_tts_amd import decoder as D, _lib
+    g = torch.Generator().manual_seed(13)
+    rnd = lambda *shape, s=1.0: torch.randn(*shape, generator=g) * s
+    C, d, B, L = 384, 3, 2, 4500
+    w = {"ru.act1.alpha": rnd(C, s=0.3), "ru.act1.beta": rnd(C, s=0.3), "ru.conv1.conv.weight": rnd(C, C, 7, s=(7 * C) ** -0.5),
+         "ru.conv1.conv.bias": rnd(C, s=0.1), "ru.act2.alpha": rnd(C, s=0.3), "ru.act2.beta": rnd(C, s=0.3),
+         "ru.conv2.conv.weight": rnd(C, C, 1, s=C ** -0.5), "ru.conv2.conv.bias": rnd(C, s=0.1)}
+    x = rnd(B, C, L)
+    xd = x.permute(0, 2, 1).contiguous().cuda()
+    want = oracle.residual_unit(x, w, "ru.", d).permute(0, 2, 1).numpy()
+    two = D.residual_unit(xd, w, "ru.", d, precision="bf16").cpu().numpy()
+    lib = _lib.load()
+    lib.q3c_debug_set_tuning(64)
+    try:
+        one = D.residual_unit(xd, w, "ru.", d, precision="bf16").cpu().numpy()
+    finally:
+        lib.q3c_debug_set_tuning(0)
+    top = float(np.abs(want).max())
+    for tag, got in (("two launches", two), ("one launch", one)):
+        assert max_abs(want, got) <= BF16_CHAIN_REL * max(top, 1.0), (tag, max_abs(want, got), top)
+
