@@ -45,7 +45,7 @@ struct ConvGemmArgs {
     const void* W2; const float* bias2;                  // [N][N] second contraction, or null
     const float* pre_a; const float* pre_invb;           // [K] with W2: SnakeBeta applied to the staged INPUT tile in LDS
     int nxb;                                             // input buffers in LDS (2 or 3): set by the launcher
-    int tile_order;                                      // 0: N tile slowest, 1: N tile fastest, 2: N tiles in pairs (set by the launcher)
+    int tile_order;                                      // 0: N tile slowest, 1: N tile fastest, G >= 2: N tiles in groups of G (set by the launcher)
     int debug;                                           // measurement aid: bit 4 = plain (not XCD-grouped) tile order
     const void* zeros;                                   // >= 16 bytes of zeros in device memory (source of out-of-sequence rows)
     long long* timeline; int timeline_slots;             // measurement aid (null normally): every 64th workgroup stores the

@@ -148,14 +148,16 @@ convgemm_kernel(const ConvGemmArgs p) {
         // slowest over the WHOLE grid (tile_order 0), so the run walks down the rows of one or two N tiles.  Layers with
         // small weights: N tile fastest (1), so the blocks sharing an input tile run side by side and it comes from
         // HBM once.
-        if (p.tile_order == 2 && !(p.debug & 32)) {
-            // N tiles in PAIRS: the run walks down the rows with the two tiles of a row side by side, so the weights of two
-            // N tiles stay in L2 (as with order 0) while each input row tile comes from HBM once per pair, not once per tile
+        if (p.tile_order >= 2 && !(p.debug & 32)) {
+            // N tiles in GROUPS of G = tile_order: the run walks down the rows with the G tiles of a row side by side, so
+            // the weights of G N tiles stay in L2 (as one does with order 0) while each input row tile comes from HBM once
+            // per group, not once per tile; the blocks of an XCD that run together form a (64 / G) x G patch of tiles
+            const int G = p.tile_order;
             const int m_tiles = gridDim.x / n_tiles, rows_all = m_tiles * gridDim.y;
-            const int full_pairs = n_tiles >> 1, in_pairs = full_pairs * 2 * rows_all;
+            const int full = n_tiles / G, in_full = full * G * rows_all;
             int nt, rest;
-            if (id < in_pairs) { const int pr = id / (2 * rows_all), r = id - pr * 2 * rows_all; nt = pr * 2 + (r & 1); rest = r >> 1; }
-            else { nt = n_tiles - 1; rest = id - in_pairs; }
+            if (id < in_full) { const int gr = id / (G * rows_all), r = id - gr * G * rows_all; rest = r / G; nt = gr * G + (r - rest * G); }
+            else { const int rem = n_tiles - full * G, r = id - in_full; rest = r / rem; nt = full * G + (r - rest * rem); }
             b = rest / m_tiles;
             n0 = nt * BN;
             m0 = (rest - b * m_tiles) * BM;
@@ -1176,9 +1178,22 @@ hipError_t launch_cfg(const ConvGemmArgs& a_in, hipStream_t s) {
     {
         const long long wbytes = (long long)a.taps * a.N * a.K * (long long)sizeof(TA);
         // weights that fit an XCD's L2 beside the streams (<= 2.5 MB): N tile fastest, the input comes from HBM once; larger
-        // ones: N tiles in pairs (two tiles' weights resident, the input once per pair; measured against N tile slowest:
+        // ones: N tiles in groups (their weights resident, the input once per group; pairs measured against N tile slowest:
         // transposed conv 768 -> 5 x 384 +8.5 %, k = 7 conv of 768 channels +0.8 %).  Tuning bit 16 = N tile slowest.
-        a.tile_order = wbytes <= (5LL << 19) ? 1 : ((::q3_convgemm_tuning & 16) ? 0 : 2);
+        if (wbytes <= (5LL << 19)) a.tile_order = 1;
+        else if (::q3_convgemm_tuning & 16) a.tile_order = 0;
+        else {
+            // group size: as many N tiles as keep their weight slices within ~3 MB of the XCD's 4 MB L2 (at least a pair),
+            // evened out over the groups (transposed conv 768 -> 5 x 384: groups of 5 against pairs +6 %)
+            const long long slice = (long long)a.taps * BN * a.K * sizeof(TA);
+            const int n_tiles = (a.N + BN - 1) / BN;
+            int gmax = (int)((3LL << 20) / slice);
+            if ((::q3_convgemm_tuning >> 16) & 15) gmax = (::q3_convgemm_tuning >> 16) & 15;
+            gmax = gmax < 2 ? 2 : gmax;
+            const int groups = (n_tiles + gmax - 1) / gmax;
+            const int g = (n_tiles + groups - 1) / groups;
+            a.tile_order = g < 2 ? 2 : g;
+        }
     }
     a.nxb = (a.taps <= 3 && round_kb(3 * xbuf) + wring <= 160 * 1024) ? 3 : 2;
     // a third input buffer is not worth a CU's second block

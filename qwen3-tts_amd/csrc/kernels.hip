@@ -4,6 +4,8 @@
 #include "common.h"
 #include <algorithm>
 
+extern int q3_convgemm_tuning;      // measurement switches (convgemm.hip); bit 256 here: the vector-ALU attention for every case
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -451,6 +453,168 @@ __global__ void __launch_bounds__(256) swa_attention_kernel(const T* __restrict_
     }
 }
 
+// The bulk decode's attention in bf16 on the matrix cores (head size 64, window <= 97, no carried rows).  One block = 128
+// consecutive queries of one (item, head), one wave per 32 of them.  The block stages the 224 key rows its queries can see
+// (rotated, bf16) and their value rows in LDS once.  A wave then computes S^T = K.Q^T for its four 32-key tiles: with keys
+// as accumulator ROWS a lane holds one query's scores, so mask, max, exp and sum are per-lane loops plus one exchange with
+// lane ^ 32, and the bf16 probabilities are, register for register, the B operand of O^T = V^T.P^T (no lane movement, no
+// LDS).  Its A operand, V^T, is read from the row-major value image by transposed LDS reads (four keys x one dimension per
+// lane and read).  Rotated queries and keys and the probabilities are rounded to bf16 (operands of the matrix cores): the
+// same roundings a bf16 run of the reference's attention makes.
+constexpr int AM_QB = 128, AM_KR = 224, AM_D = 64;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned am_pack2(float a, float b) {
+    const bf16 x = (bf16)a, y = (bf16)b;
+    return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+}
+// rotary embedding of eight (e, e + half) pairs: lo holds dimensions e .. e+7, hi their partners
+__device__ __forceinline__ void am_rope8(const uint4& lo, const uint4& hi, const float* __restrict__ cr, const float* __restrict__ sr,
+                                         uint4& olo, uint4& ohi) {
+    const float4 c0 = *(const float4*)cr, c1 = *(const float4*)(cr + 4), s0 = *(const float4*)sr, s1 = *(const float4*)(sr + 4);
+    const float c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    float l[8], hgh[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const float x1 = (float)((const bf16*)&lo)[u], x2 = (float)((const bf16*)&hi)[u];
+        l[u] = x1 * c[u] - x2 * sn[u];
+        hgh[u] = x2 * c[u] + x1 * sn[u];
+    }
+    olo = make_uint4(am_pack2(l[0], l[1]), am_pack2(l[2], l[3]), am_pack2(l[4], l[5]), am_pack2(l[6], l[7]));
+    ohi = make_uint4(am_pack2(hgh[0], hgh[1]), am_pack2(hgh[2], hgh[3]), am_pack2(hgh[4], hgh[5]), am_pack2(hgh[6], hgh[7]));
+}
+// LDS images, 128-byte rows of eight 16-byte chunks.  Keys are read by rows (16 bytes per lane, 32 consecutive rows per
+// half wave): chunk ^ ((row >> 1) & 7).  Values are read transposed (a half wave takes 4 rows x 64 bytes): chunk ^ 4 on rows
+// 2, 3 of every four puts the 16 pieces on distinct banks.
+__device__ __forceinline__ int am_off_k(int row, int ch) { return 128 * row + 16 * (ch ^ ((row >> 1) & 7)); }
+__device__ __forceinline__ int am_off_v(int row, int ch) { return 128 * row + 16 * (ch ^ (((row >> 1) & 1) << 2)); }
+
+__global__ void __launch_bounds__(256) swa_attention_mfma_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                                 const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                                                 int Tn, int nh, int nkv, int window, float scale, int max_pos) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_att[];
+    unsigned char* Ki = smem_att;
+    unsigned char* Vi = smem_att + AM_KR * 128;
+    const int q0 = blockIdx.x * AM_QB, h = blockIdx.y, b = blockIdx.z;
+    const int hk = h / (nh / nkv);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rs = (nh + 2 * nkv) * AM_D;
+    const bf16* base = qkv + (size_t)b * Tn * rs;
+    const int k_lo = q0 - 96;                                   // key of image row 0; wave w reads rows 32w .. 32w + 127
+    const int waves_on = min(4, (Tn - q0 + 31) >> 5);
+    const int rows = 96 + 32 * waves_on;
+    for (int i = tid; i < rows * 4; i += 256) {                 // keys: one (row, 8-dimension group and its partner) per thread
+        const int r = i >> 2, g = i & 3, pos = k_lo + r;
+        uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
+        if (pos >= 0 && pos < Tn) {
+            const bf16* kr = base + (size_t)pos * rs + (nh + hk) * AM_D + 8 * g;
+            const int ap = min(pos, max_pos - 1);
+            am_rope8(*(const uint4*)kr, *(const uint4*)(kr + 32), cos_t + (size_t)ap * 32 + 8 * g, sin_t + (size_t)ap * 32 + 8 * g, lo, hi);
+        }
+        *(uint4*)(Ki + am_off_k(r, g)) = lo;
+        *(uint4*)(Ki + am_off_k(r, 4 + g)) = hi;
+    }
+    for (int i = tid; i < rows * 8; i += 256) {                 // values: rows past the ends are zeros (a probability of 0 times
+        const int r = i >> 3, ch = i & 7, pos = k_lo + r;       // whatever the LDS held would still be NaN for NaN bits)
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (pos >= 0 && pos < Tn) v = *(const uint4*)(base + (size_t)pos * rs + (nh + nkv + hk) * AM_D + 8 * ch);
+        *(uint4*)(Vi + am_off_v(r, ch)) = v;
+    }
+    __syncthreads();
+    const int qw0 = q0 + 32 * wave;
+    if (qw0 >= Tn) return;                                      // whole waves only: the transposed reads need every lane
+    const int r = lane & 31, hh = lane >> 5;
+    const int qi = qw0 + r, qc = min(qi, Tn - 1);
+    // the query fragments straight from memory: k-step s of lane (r, hh) is dimensions 16 s + 8 hh .. + 7 of query r, and
+    // steps s, s + 2 hold each other's rotation partners
+    bf16x8 qf[4];
+    {
+        const bf16* qr = base + (size_t)qc * rs + h * AM_D + 8 * hh;
+        const int ap = min(qc, max_pos - 1);
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+            uint4 lo, hi;
+            am_rope8(*(const uint4*)(qr + 16 * sp), *(const uint4*)(qr + 16 * sp + 32), cos_t + (size_t)ap * 32 + 16 * sp + 8 * hh,
+                     sin_t + (size_t)ap * 32 + 16 * sp + 8 * hh, lo, hi);
+            qf[sp] = __builtin_bit_cast(bf16x8, lo);
+            qf[sp + 2] = __builtin_bit_cast(bf16x8, hi);
+        }
+    }
+    const int krow0 = 32 * wave;
+    f32x16 sacc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sacc[t][i] = 0.f;
+        const int row = krow0 + 32 * t + r;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8 a = *(const bf16x8*)(Ki + am_off_k(row, 2 * s + hh));
+            sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], sacc[t], 0, 0, 0);
+        }
+    }
+    // register i of tile t is key k_lo + krow0 + 32 t + 8 (i >> 2) + 4 hh + (i & 3)
+    const int key_min = max(0, qi - window + 1);
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int kpos = k_lo + krow0 + 32 * t + 8 * (i >> 2) + 4 * hh + (i & 3);
+            const float x = (kpos >= key_min && kpos <= qi) ? sacc[t][i] * scale : -INFINITY;
+            sacc[t][i] = x;
+            m = fmaxf(m, x);
+        }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float sum = 0.f;
+    bf16x8 pf[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float pv = __expf(sacc[t][i] - m);
+            sum += pv;
+            pf[t][i >> 3][i & 7] = (bf16)pv;
+        }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    f32x16 oacc[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[n][i] = 0.f;
+    const int q4 = (lane >> 2) & 3, p4 = lane & 3, c16 = (lane >> 4) & 1;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                bf16x8 a;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int row = krow0 + 32 * t + 16 * s2 + 8 * jj + 4 * hh + q4;
+                    const unsigned char* ad = Vi + am_off_v(row, 4 * n + 2 * c16 + (p4 >> 1)) + 8 * (p4 & 1);
+                    const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)ad);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[4 * jj + e] = v[e];
+                }
+                oacc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf[t][s2], oacc[n], 0, 0, 0);
+            }
+    if (qi < Tn) {
+        bf16* orow = out + ((size_t)b * Tn + qi) * ((size_t)nh * AM_D) + h * AM_D + 4 * hh;
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 w;
+                w.x = am_pack2(oacc[n][4 * g] * inv, oacc[n][4 * g + 1] * inv);
+                w.y = am_pack2(oacc[n][4 * g + 2] * inv, oacc[n][4 * g + 3] * inv);
+                *(uint2*)(orow + 32 * n + 8 * g) = w;
+            }
+    }
+}
+
 // The single new query of a frame-rate push (one frame per stream and launch sequence): one wave per (stream, head), no
 // staging and no workgroup barrier.  Scores: lane = key, each lane reads its key's row where it lives (the slot's ring
 // buffer, or the new row for the query's own frame), rotates it by its frame number and dots it with the rotated query
@@ -738,6 +902,15 @@ hipError_t q3_launch_swa_attention(const void* qkv, void* out, const float* cos_
         else
             hipLaunchKernelGGL(swa_attention_step_kernel<float>, grid1, dim3(256), lds1, s, (const float*)qkv, (float*)out, cos_t, sin_t, nh, nkv,
                                d, window, scale1, hist, pos0, max_pos, ring);
+        return hipGetLastError();
+    }
+    if (dtype == Q3_BF16 && d == AM_D && hist == 0 && !pos0 && window >= 1 && window <= 97 && nkv > 0 && nh % nkv == 0 && !(q3_convgemm_tuning & 256)) {
+        const size_t ldsm = (size_t)2 * AM_KR * 128;
+        auto km = swa_attention_mfma_kernel;
+        hipError_t em = hipFuncSetAttribute((const void*)km, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm);
+        if (em != hipSuccess) return em;
+        dim3 gridm((T + AM_QB - 1) / AM_QB, nh, B);
+        hipLaunchKernelGGL(km, gridm, dim3(256), ldsm, s, (const bf16*)qkv, (bf16*)out, cos_t, sin_t, T, nh, nkv, window, 1.0f / sqrtf((float)d), max_pos);
         return hipGetLastError();
     }
     if (window < 1 || window + 3 > 64 * ATT_MAXC || (d & 3) || d > 256) return hipErrorInvalidValue;    // rows are read 16 bytes at a time

@@ -63,6 +63,33 @@ def _rms(x):
     return float(np.sqrt(np.mean(np.asarray(x, dtype=np.float64) ** 2)))
 
 
+# ---- the bulk attention on the matrix cores -------------------------------------------------------------------------------
+BF16_TRANSFORMER_SNR_DB = 36.0       # measured 37.9-38.9 dB for both attention kernels
+
+
+@pytest.mark.parametrize("T", [1, 31, 72, 73, 129, 300])
+def test_flagship_transformer_bf16_both_attention_kernels_vs_oracle(flagship, flagship_bf16, T):
+    """The transformer stack (8 layers, 16 heads x 64, window 72) in bf16 on random hidden states against the oracle, with the
+    matrix-core attention kernel the bulk decode uses and with the vector-ALU kernel (the library's measurement switch): both
+    within the same floor, lengths covering one query, partial 32-query and 128-query tiles, the window edge and a full
+    chunk."""
+    cfg, w = flagship
+    x = torch.randn(2, T, cfg.latent_dim, generator=torch.Generator().manual_seed(100 + T))
+    want = oracle.transformer(cfg, x, w).numpy()
+    lib = _lib.load()
+    got = {}
+    try:
+        for name, bits in (("matrix cores", 0), ("vector ALU", 256)):
+            lib.q3c_debug_set_tuning(bits)
+            got[name] = flagship_bf16.transformer(x).cpu().numpy()
+    finally:
+        lib.q3c_debug_set_tuning(0)
+    for name, y in got.items():
+        assert np.isfinite(y).all(), name
+        assert snr_db(want, y) >= BF16_TRANSFORMER_SNR_DB, (name, T, snr_db(want, y))
+    print(f"transformer bf16 T={T}: " + ", ".join(f"{k} {snr_db(want, v):.1f} dB" for k, v in got.items()))
+
+
 # ---- configs[0]: one 10 s utterance, and the window edge ---------------------------------------------------------------
 @pytest.mark.parametrize("T", [125, 73])
 def test_flagship_forward_vs_oracle(flagship, flagship_bf16, T):

@@ -154,12 +154,21 @@ def test_stream_errors():
 def test_flagship_bf16_streams_track_the_bulk_forward():
     """Flagship widths in bf16: the segmented-row kernels at the channel counts of the headline benchmark.  Streaming and
     bulk round the same bf16 intermediates except where fp32 reductions group differently, so they agree far more
-    closely (measured 37 dB) than bf16 agrees with fp32 (15-18 dB with these random weights); bound: 30 dB."""
+    closely (measured 37 dB) than bf16 agrees with fp32 (15-18 dB with these random weights); bound: 30 dB.  The bulk
+    forward runs with the vector-ALU attention here (the library's measurement switch), the arithmetic the streaming pushes
+    use: the bulk decode's matrix-core attention rounds queries, keys and probabilities to bf16, one more bf16-sized
+    difference that these random weights amplify to the 16 dB every bf16 run has against the oracle (both attention kernels
+    are held to the oracle in test_gpu_configs.py)."""
     cfg = q3.flagship_config()
     dec, _ = _decoder(cfg, precision="bf16", seed=1)
     T = 30
     codes = q3.random_codes(cfg, 2, T, seed=9)
-    ref = dec.forward(codes)[:, 0].float()
+    lib = _lib.load()
+    lib.q3c_debug_set_tuning(256)
+    try:
+        ref = dec.forward(codes)[:, 0].float()
+    finally:
+        lib.q3c_debug_set_tuning(0)
     pool = dec.open_streams(4)
     ids = pool.open_many(2)
     outs, t = [], 0
