@@ -44,6 +44,10 @@ struct ConvGemmArgs {
                                                          // row r >= seg_hist goes to batch item j, row r - seg_hist of Y / Y2 / R
     const void* W2; const float* bias2;                  // [N][N] second contraction, or null
     const float* pre_a; const float* pre_invb;           // [K] with W2: SnakeBeta applied to the staged INPUT tile in LDS
+    const void* W3; float* P; long long p_batch_stride;  // with W2, bf16, one column tile per wave: the output is NOT stored;
+                                                         // instead P[b, m, t] = sum_n post(y)[b, m, n] * W3[t][n] for the 8 taps t of
+                                                         // a following one-channel conv (W3: [16][N], rows >= its tap count zero;
+                                                         // P rows of 8 floats), which q3_launch_tap_sum then sums along the diagonal
     int nxb;                                             // input buffers in LDS (2 or 3): set by the launcher
     int tile_order;                                      // 0: N tile slowest, 1: N tile fastest, G >= 2: N tiles in groups of G (set by the launcher)
     int debug;                                           // measurement aid: bit 4 = plain (not XCD-grouped) tile order
@@ -71,6 +75,9 @@ hipError_t q3_launch_rvq_encode(const float* emb, int B, int T, int in_dim, int 
                                 long long* codes, hipStream_t s);
 hipError_t q3_launch_mean_embedding(const long long* codes, int B, int Q, int T, int bins, int H,
                                     const float* table, void* out, int out_dtype, int* err_flag, hipStream_t s);
+// y[b, m] = act(bias + sum_t P[b, m - (taps - 1) + t, t]) over the rows m - (taps - 1) + t >= 0: the one-channel causal conv
+// whose per-tap products a fused unit left in P ([B][M][8] fp32); act: Q3_ACT_NONE or Q3_ACT_CLAMP
+hipError_t q3_launch_tap_sum(const float* P, const float* bias, float* y, int B, int M, int taps, int act, hipStream_t s);
 hipError_t q3_launch_rmsnorm(const void* x, const float* w, void* y, long long rows, int H, float eps, int dtype, hipStream_t s);
 // `hist` carried rows sit in front of each item's L rows of x (0: rows before the sequence are zero padding)
 hipError_t q3_launch_dwconv_ln(const void* x, const float* w /*[7][C], tap-major*/, const float* b, const float* lnw, const float* lnb,

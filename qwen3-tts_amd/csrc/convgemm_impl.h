@@ -902,8 +902,41 @@ convgemm_kernel(const ConvGemmArgs p) {
     //            (column-wise: the per-channel parameters are two registers per lane)
     //   phase 2  slab A -> Y, slab B -> Y2           (row-wise, 16-byte stores)
     // Branch-free form for full tiles (see `full` above): same three phases, every load and store unconditional.
-    auto fast_epilogue = [&](auto dual_tag) {
+    // Fold of a following one-channel conv (p.W3): a pass's 16 rows x SCOLS channels of post(y) sit in slab A as fp32; instead of
+    // storing them, the wave multiplies them by the conv's taps: P^T[tap][row] = W3[tap][:] . z[row][:] on the 16x16x32 matrix
+    // op (A = W3, 16 taps x 32 channels per step; B = the slab rows, read 32 bytes per lane and rounded to bf16 exactly as the
+    // stored tensor would have been).  Lane (row = lane & 15, g = lane >> 4) ends with taps 4g .. 4g+3 of its row: lanes 0-31
+    // store the row's 8 floats.
+    constexpr bool FOLD_OK = FUSE2 && sizeof(TA) == 2 && WAVES_N == 1 && WN == JG && !SEG;
+    constexpr int FOLD_KS = SCOLS / 32;
+    const bool fold = FOLD_OK && p.W3 != nullptr;
+    float* __restrict__ Pb = (FOLD_OK && p.P) ? p.P + (long long)b * p.p_batch_stride : nullptr;
+    bf16x8 w3f[FOLD_OK ? FOLD_KS : 1];
+    if constexpr (FOLD_OK) {
+        if (fold) {
+#pragma unroll
+            for (int ks = 0; ks < FOLD_KS; ++ks)
+                w3f[ks] = *(const bf16x8*)((const bf16*)p.W3 + (size_t)(lane & 15) * p.N + 32 * ks + 8 * (lane >> 4));
+        }
+    }
+    auto fold_pass = [&](int mrow0, bool row_ok) {
+        if constexpr (FOLD_OK) {
+            f32x4 pacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < FOLD_KS; ++ks) {
+                const float* sp = slabA + (lane & 15) * SLD + 32 * ks + 8 * (lane >> 4);
+                const float4 t0 = *(const float4*)sp, t1 = *(const float4*)(sp + 4);
+                bf16x8 z;
+                z[0] = (bf16)t0.x; z[1] = (bf16)t0.y; z[2] = (bf16)t0.z; z[3] = (bf16)t0.w;
+                z[4] = (bf16)t1.x; z[5] = (bf16)t1.y; z[6] = (bf16)t1.z; z[7] = (bf16)t1.w;
+                pacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3f[ks], z, pacc, 0, 0, 0);
+            }
+            if (lane < 32 && row_ok) *(f32x4*)(Pb + (long long)(mrow0 + (lane & 15)) * 8 + 4 * (lane >> 4)) = pacc;
+        }
+    };
+    auto fast_epilogue = [&](auto dual_tag, auto fold_tag) {
         constexpr bool DUAL = decltype(dual_tag)::value;
+        constexpr bool FOLD = decltype(fold_tag)::value;
         if (!FUSE2 && has_res) r_fetch_full(0);
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
@@ -916,7 +949,7 @@ convgemm_kernel(const ConvGemmArgs p) {
                     if (has_res) {
                         // since the request: this tile's earlier work and waits (first pass) or one pass's stores
                         if (pidx == 0) wait_vmcnt_c<0>();
-                        else wait_vmcnt_c<NPIECE * (DUAL ? 2 : 1)>();
+                        else wait_vmcnt_c<FOLD ? 1 : NPIECE * (DUAL ? 2 : 1)>();
                         r_pin();
 #pragma unroll
                         for (int k = 0; k < NPIECE; ++k) {
@@ -969,8 +1002,9 @@ convgemm_kernel(const ConvGemmArgs p) {
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
+                    if constexpr (FOLD) fold_pass(mrow0, true);
 #pragma unroll
-                    for (int k = 0; k < NPIECE; ++k) {
+                    for (int k = 0; k < (FOLD ? 0 : NPIECE); ++k) {
                         const int id = lane + 64 * k;
                         const int row = id / CPRW_F, ch = id - row * CPRW_F;
                         const long long yo = (long long)(mrow0 + row) * p.ldy + ncol0 + ch * EPO;
@@ -994,7 +1028,10 @@ convgemm_kernel(const ConvGemmArgs p) {
         }
     };
     if (full) {
-        if (Y2b) fast_epilogue(std::true_type{}); else fast_epilogue(std::false_type{});
+        if constexpr (FOLD_OK) {
+            if (fold) { fast_epilogue(std::false_type{}, std::true_type{}); mark(5); return; }
+        }
+        if (Y2b) fast_epilogue(std::true_type{}, std::false_type{}); else fast_epilogue(std::false_type{}, std::false_type{});
         mark(5);
         return;
     }
@@ -1112,6 +1149,13 @@ convgemm_kernel(const ConvGemmArgs p) {
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
+                if constexpr (FOLD_OK) {
+                    if (fold) {      // partial tiles: the same product, rows past the sequence are not stored
+                        fold_pass(mrow0, mrow0 + (lane & 15) < p.M);
+                        __builtin_amdgcn_wave_barrier();
+                        continue;
+                    }
+                }
                 // phase 2: slabs -> memory, 16 bytes per lane
                 for (int id = lane; id < SROWS * cprw; id += 64) {
                     const int row = id / cprw, ch = id - row * cprw;
@@ -1171,6 +1215,8 @@ hipError_t launch_cfg(const ConvGemmArgs& a_in, hipStream_t s) {
     const int xi_total = (HR * CPR + NTHR - 1) / NTHR;
     const int xps = (xi_total + a.taps - 1) / a.taps;
     if (xps > (BM * CPR + NTHR - 1) / NTHR || xps > 4) return hipErrorInvalidValue;      // halo too large for the staged-slice scheme
+    if (a.W3 && !(FUSE2 && sizeof(TA) == 2 && WAVES_N == 1 && WN == JG && a.P && a.post_a && !a.Y2 && a.seg_len == 0 && a.N % 32 == 0 && a.N == BN))
+        return hipErrorInvalidValue;
     if (FUSE2 && (a.N > BN || a.K != a.N || !a.W2 || a.act != Q3_ACT_SNAKE || !a.epi_a || !a.epi_invb || !a.pre_a || !a.pre_invb || !a.R ||
                   a.ldy % 8 || a.ldr % 8 || a.N % 8))
         return hipErrorInvalidValue;

@@ -16,6 +16,8 @@
 // device and everything after that goes through the pointer it returned.
 static __device__ __align__(256) unsigned char q3c_static_scratch[Q3C_STATIC_SCRATCH_BYTES];
 
+extern int q3_convgemm_tuning;      // measurement switches (convgemm.hip); bit 512 here: the final conv as its own launch
+
 namespace {
 
 struct HostTensor { std::vector<int64_t> shape; std::vector<float> data; };
@@ -72,6 +74,8 @@ struct q3c_ctx {
     std::vector<Block> blocks;
     Snake final_snake;
     GemmW conv_out;
+    void* conv_out_fold = nullptr;    // bf16 contexts: conv_out's taps as [16][channels] (rows past its 7 taps zero), the operand of the
+                                      // last residual unit's folded product (ConvGemmArgs::W3)
 
     int device = -1;                  // the device that was current in q3c_finalize
     void* static_scratch = nullptr;   // address of q3c_static_scratch on that device
@@ -261,6 +265,8 @@ struct GemmOpts {
     void* Y2 = nullptr;               // second output: Y gets the pre-`post` value, Y2 the post value
     const GemmW* second = nullptr;    // fused 1x1 second contraction (residual unit in one launch)
     const Snake* pre = nullptr;       // with `second`: SnakeBeta applied to the staged input tile (the unit reads the raw stream)
+    const void* fold_w = nullptr;     // with `second` and `post`: the output is not stored; its products with the 16 rows of fold_w
+    float* fold_p = nullptr;          // go to fold_p, [B][M][8] fp32 (the following one-channel conv, finished by q3_launch_tap_sum)
     // Streaming layouts.  `segmented`: the B items' rows are stacked in one row space, each item = x_hist carried rows
     // followed by its L_in new rows, and only new rows produce output.  Offsets / strides are in elements of the
     // respective tensor; a stride of 0 means dense ([B][M][n_out]).
@@ -292,6 +298,7 @@ int gemm(q3c_ctx* c, const GemmW& g, const void* X, int B, int L_in, void* Y, in
     if (o.second) {
         if (!o.pre) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "fused residual unit without its input SnakeBeta");
         a.W2 = o.second->w; a.bias2 = o.second->bias; a.pre_a = o.pre->a; a.pre_invb = o.pre->invb;
+        if (o.fold_w) { a.W3 = o.fold_w; a.P = o.fold_p; a.p_batch_stride = (long long)M * 8; }
     }
     if (o.segmented) {
         if (M != L_in) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "segmented contraction needs as many output as input rows");
@@ -960,6 +967,14 @@ int q3c_finalize(q3c_ctx* c) {
     const int nb = k.num_upsample_rates;
     TRY(pack_snake(c, "decoder." + std::to_string(nb + 1) + ".", ch, &c->final_snake));
     TRY(pack_conv(c, "decoder." + std::to_string(nb + 2) + ".conv", 1, ch, 7, 1, dt, &c->conv_out));
+    if (dt == Q3_BF16) {
+        int rc = 0;
+        GETW(wf, "decoder." + std::to_string(nb + 2) + ".conv.weight", 1, ch, 7);
+        std::vector<float> p16((size_t)16 * ch, 0.f);
+        for (int ci = 0; ci < ch; ++ci)
+            for (int t = 0; t < 7; ++t) p16[(size_t)t * ch + ci] = wf->data[(size_t)ci * 7 + t];
+        TRY(upload_typed(c, p16, Q3_BF16, &c->conv_out_fold));
+    }
     HIPCHK(c, hipGetDevice(&c->device));
     {   // this device's copy of the static workspace (every GPU has its own, at its own address)
         void* sp = nullptr;
@@ -1125,6 +1140,12 @@ static int forward_impl(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, 
     // global -> LDS by DMA); the raw residual stream `raw` is kept beside it and updated in place.
     int ch = k.decoder_dim;
     void* free_bufs[3] = {other, bufC, base + lay.oD};
+    bool folded = false;
+    const int ch_last = k.decoder_dim >> c->blocks.size();
+    const auto last_tap = c->taps.find(Q3C_STAGE_BLOCK0 + (int)c->blocks.size() - 1);
+    // (a tap on the last block's output needs that tensor in memory; the fold needs one column tile to hold every channel)
+    const bool fold_final = c->conv_out_fold && c->fuse_units && dt == Q3_BF16 && (ch_last == 96 || ch_last == 32) && c->conv_out.taps <= 8 &&
+                            (last_tap == c->taps.end() || !last_tap->second.first) && !(q3_convgemm_tuning & 512);
     for (size_t i = 0; i < c->blocks.size(); ++i) {
         const Block& b = c->blocks[i];
         if (L < 2) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "sequence too short for the transposed convolutions");
@@ -1149,6 +1170,9 @@ static int forward_impl(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, 
                 // consumer's SnakeBeta (the next block's head, or the final one), to its single output
                 GemmOpts g; g.act = Q3_ACT_SNAKE; g.epi = &u.a2; g.second = &u.c2; g.pre = &u.a1; g.R = raw;
                 if (last) g.post = post;
+                // The decoder's last unit: its output (final SnakeBeta applied) is read by the one-channel final conv alone, so
+                // it is never stored: the unit's epilogue leaves the conv's per-tap products, 8 floats per row, in `sn`.
+                if (last && i + 1 == c->blocks.size() && fold_final) { g.fold_w = c->conv_out_fold; g.fold_p = (float*)sn; folded = true; }
                 TRY(gemm(c, u.c1, raw, B, L, sn, L, dt, g, s));
                 if (!last) std::swap(raw, sn);     // the last unit's (snaked) output stays in `sn`: the block's output
             } else {
@@ -1162,9 +1186,12 @@ static int forward_impl(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, 
         // the block's output (next SnakeBeta applied) is in `sn`
         free_bufs[0] = cur; free_bufs[1] = raw; free_bufs[2] = sp;
         cur = sn;
-        TRY(tap_out(c, Q3C_STAGE_BLOCK0 + (int)i, cur, (size_t)B * L * ch, s));
+        if (!(folded && i + 1 == c->blocks.size())) TRY(tap_out(c, Q3C_STAGE_BLOCK0 + (int)i, cur, (size_t)B * L * ch, s));
     }
-    {   // final conv to one channel, clamp fused, fp32 samples out
+    if (folded) {   // the final conv's taps summed along the diagonal of the products, bias, clamp
+        LAUNCH_B(c, s, "tap_sum", (size_t)B * L * 36,
+                 q3_launch_tap_sum((const float*)cur, c->conv_out.bias, wav, B, L, c->conv_out.taps, Q3_ACT_CLAMP, s));
+    } else {        // final conv to one channel, clamp fused, fp32 samples out
         GemmOpts g; g.act = Q3_ACT_CLAMP;
         TRY(gemm(c, c->conv_out, cur, B, L, wav, L, Q3_F32, g, s));
     }

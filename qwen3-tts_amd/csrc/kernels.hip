@@ -453,6 +453,30 @@ __global__ void __launch_bounds__(256) swa_attention_kernel(const T* __restrict_
     }
 }
 
+// The one-channel causal conv whose per-tap products P[b][m][t] = w_t . z[b][m] a fused unit left behind (8 floats per row):
+// y[b][m] = act(bias + sum_t P[b][m - (taps - 1) + t][t]).  A block stages its 256 rows and the 8 before them in LDS (rows of
+// 9 floats: the diagonal reads of consecutive lanes then fall on distinct banks).
+__global__ void __launch_bounds__(256) tap_sum_kernel(const float* __restrict__ P, const float* __restrict__ bias, float* __restrict__ y,
+                                                      int M, int taps, int act) {
+    __shared__ float sm[(256 + 8) * 9];
+    const long long b = blockIdx.y;
+    const int m0 = blockIdx.x * 256, tid = threadIdx.x;
+    const float4* Pb = (const float4*)(P + b * (long long)M * 8);
+    for (int i = tid; i < (256 + 8) * 2; i += 256) {
+        const int lr = i >> 1, row = m0 - 8 + lr;
+        const float4 v = (row >= 0 && row < M) ? Pb[(long long)row * 2 + (i & 1)] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float* d = sm + lr * 9 + 4 * (i & 1);
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    const int m = m0 + tid;
+    if (m >= M) return;
+    float a = bias ? bias[0] : 0.f;
+    for (int t = 0; t < taps; ++t) a += sm[(tid + 8 - (taps - 1) + t) * 9 + t];
+    if (act == Q3_ACT_CLAMP) a = fminf(1.0f, fmaxf(-1.0f, a));
+    y[b * (long long)M + m] = a;
+}
+
 // The bulk decode's attention in bf16 on the matrix cores (head size 64, window <= 97, no carried rows).  One block = 128
 // consecutive queries of one (item, head), one wave per 32 of them.  The block stages the 224 key rows its queries can see
 // (rotated, bf16) and their value rows in LDS once.  A wave then computes S^T = K.Q^T for its four 32-key tiles: with keys
@@ -929,6 +953,13 @@ hipError_t q3_launch_swa_attention(const void* qkv, void* out, const float* cos_
         if (lds > 48 * 1024 && (e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
         hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const float*)qkv, (float*)out, cos_t, sin_t, hist + T, nh, nkv, d, window, scale, hist, pos0, max_pos, ring);
     }
+    return hipGetLastError();
+}
+
+hipError_t q3_launch_tap_sum(const float* P, const float* bias, float* y, int B, int M, int taps, int act, hipStream_t s) {
+    if (B == 0 || M == 0) return hipSuccess;
+    if (taps < 1 || taps > 8 || B > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(tap_sum_kernel, dim3((M + 255) / 256, B), dim3(256), 0, s, P, bias, y, M, taps, act);
     return hipGetLastError();
 }
 

@@ -90,6 +90,25 @@ def test_flagship_transformer_bf16_both_attention_kernels_vs_oracle(flagship, fl
     print(f"transformer bf16 T={T}: " + ", ".join(f"{k} {snr_db(want, v):.1f} dB" for k, v in got.items()))
 
 
+def test_final_conv_folded_into_the_last_unit_equals_its_own_launch(flagship, flagship_bf16):
+    """The bulk bf16 decode never stores the last residual unit's output: its epilogue leaves the final conv's per-tap products
+    (8 floats per row) and a diagonal-sum kernel finishes the conv.  Same bf16 inputs to the conv's products, fp32 sums in
+    another order: equal to the separate final-conv launch (the library's measurement switch) to fp32 rounding, on full and
+    partial tiles (two items of 125 frames: 239 445 rows each) and on a 3-frame item (one partial tile)."""
+    cfg, _ = flagship
+    lib = _lib.load()
+    for B, T in ((2, 125), (1, 3)):
+        codes = q3.random_codes(cfg, B, T, seed=40 + T).cuda()
+        try:
+            lib.q3c_debug_set_tuning(512)
+            want = flagship_bf16.forward(codes).cpu().numpy()
+        finally:
+            lib.q3c_debug_set_tuning(0)
+        got = flagship_bf16.forward(codes).cpu().numpy()
+        assert got.shape == want.shape == (B, 1, cfg.output_length(T))
+        assert np.isfinite(got).all() and max_abs(want, got) <= 2e-6, max_abs(want, got)
+
+
 # ---- configs[0]: one 10 s utterance, and the window edge ---------------------------------------------------------------
 @pytest.mark.parametrize("T", [125, 73])
 def test_flagship_forward_vs_oracle(flagship, flagship_bf16, T):
