@@ -128,6 +128,74 @@ def make_rvq_encode():
 
 
 # ---------------------------------------------------------------------------------------------
+def mimi_for_encoder(ecfg, cfg, w):
+    """The sibling's MimiModel with the encoder sizes of `ecfg`, the quantiser sizes of `cfg` and the tensors of `w`."""
+    import math
+    hop = math.prod(ecfg.ratios)
+    mc = MimiConfig(audio_channels=1, hidden_size=ecfg.hidden_size, num_filters=ecfg.num_filters, num_residual_layers=1,
+                    upsampling_ratios=list(ecfg.ratios[::-1]), kernel_size=ecfg.kernel_size, last_kernel_size=ecfg.last_kernel_size,
+                    residual_kernel_size=ecfg.residual_kernel_size, dilation_growth_rate=2, use_causal_conv=True, pad_mode="constant",
+                    compress=ecfg.compress, trim_right_ratio=1.0, codebook_size=cfg.codebook_size, codebook_dim=cfg.codebook_dim,
+                    vector_quantization_hidden_dimension=cfg.codebook_dim, num_quantizers=cfg.num_quantizers,
+                    num_semantic_quantizers=cfg.num_semantic_quantizers, sampling_rate=24000, frame_rate=24000 / hop / ecfg.downsample_stride,
+                    num_hidden_layers=ecfg.num_hidden_layers, num_attention_heads=ecfg.num_attention_heads,
+                    num_key_value_heads=ecfg.num_attention_heads, head_dim=ecfg.head_dim, intermediate_size=ecfg.intermediate_size,
+                    hidden_act="gelu", norm_eps=ecfg.norm_eps, sliding_window=ecfg.sliding_window, rope_theta=ecfg.rope_theta,
+                    use_conv_shortcut=False, use_cache=False, use_streaming=False, attn_implementation="eager",
+                    upsample_groups=ecfg.hidden_size)
+    m = mimi.MimiModel(mc).eval()
+    sd = {k: v for k, v in w.items() if k.startswith(("encoder.", "encoder_transformer.", "downsample."))}
+    for grp, attr in (("semantic", "semantic_residual_vector_quantizer"), ("acoustic", "acoustic_residual_vector_quantizer")):
+        n = cfg.num_semantic_quantizers if grp == "semantic" else cfg.num_quantizers - cfg.num_semantic_quantizers
+        for i in range(n):
+            sd[f"quantizer.{attr}.layers.{i}.codebook.embed_sum"] = w[f"quantizer.{grp}.layers.{i}.embed_sum"]
+            sd[f"quantizer.{attr}.layers.{i}.codebook.cluster_usage"] = w[f"quantizer.{grp}.layers.{i}.cluster_usage"]
+            sd[f"quantizer.{attr}.layers.{i}.codebook.initialized"] = torch.tensor([1.0])
+        sd[f"quantizer.{attr}.input_proj.weight"] = w[f"quantizer.{grp}.input_proj.weight"]
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert not [k for k in missing if k.startswith(("encoder.", "encoder_transformer.", "downsample.")) or "input_proj" in k or "codebook" in k], missing
+    return m
+
+
+def make_encoder():
+    """The tokenizer's ENCODE side: the sibling MimiModel.encode (conv encoder, transformer, stride-2 conv, split-RVQ encode) on
+    seeded audio, at small sizes; expected = its codes and the embeddings it quantises.  Lengths include ones that no stride
+    divides (every strided conv pads on the right) and one shorter than a frame."""
+    import importlib
+    E = importlib.import_module("qwen3-tts_amd.encoder")
+    import encoder_oracle as eo
+    g = torch.Generator().manual_seed(57)
+    for tag, ekw, dkw, lengths in (
+            ("encoder_tiny", dict(), dict(codebook_size=32, num_quantizers=4, num_semantic_quantizers=1, codebook_dim=8, rvq_out_dim=32), (240, 101, 7)),
+            ("encoder_wide", dict(num_filters=16, ratios=(2, 2, 3), hidden_size=64, num_attention_heads=2, head_dim=32, intermediate_size=128,
+                                  num_hidden_layers=2, sliding_window=9),
+             dict(codebook_size=64, num_quantizers=8, num_semantic_quantizers=1, codebook_dim=16, rvq_out_dim=64), (1200, 613))):
+        ecfg = E.tiny_encoder_config(**ekw)
+        cfg = q3.tiny_config(**dkw)
+        w = {**q3.synthetic_weights(cfg, seed=17), **E.synthetic_encoder_weights(ecfg, cfg.codebook_dim, seed=19)}
+        m = mimi_for_encoder(ecfg, cfg, w)
+        arrays = {}
+        for L in lengths:
+            audio = torch.randn(2, 1, L, generator=g) * 0.5
+            with torch.no_grad():
+                emb = m.encoder(audio)
+                emb = m.encoder_transformer(emb.transpose(1, 2), return_dict=False)[0].transpose(1, 2)
+                emb = m.downsample(emb)
+                codes = m.encode(audio, return_dict=False)[0]
+            assert codes.shape == (2, cfg.num_quantizers, ecfg.frames(L)), (codes.shape, ecfg.frames(L))
+            got_codes, got_emb = eo.encode(ecfg, cfg, w, audio)
+            assert torch.allclose(got_emb, emb, atol=2e-5, rtol=1e-4), float((got_emb - emb).abs().max())
+            agree = float((got_codes == codes).float().mean())
+            assert agree >= 0.99, agree                      # a near-tie may fall either way under another summation order
+            arrays[f"audio_{L}"] = audio
+            arrays[f"emb_{L}"] = emb
+            arrays[f"codes_{L}"] = codes
+        save(tag, dict(encoder_config=ecfg.to_dict(), config=cfg.to_dict(), weight_seeds=[17, 19], weight_abs_sum=wsum(w), lengths=list(lengths)),
+             **arrays)
+
+
+# ---------------------------------------------------------------------------------------------
 def make_primitives():
     g = torch.Generator().manual_seed(21)
     arrays, meta = {}, {"cases": []}
@@ -289,8 +357,13 @@ def make_transformer_parts():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:                 # only the named fixtures, e.g. `make_goldens.py make_encoder`
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     make_rvq()
     make_rvq_encode()
+    make_encoder()
     make_primitives()
     make_decoder()
     make_transformer_parts()

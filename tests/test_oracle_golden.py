@@ -53,6 +53,36 @@ def test_rvq_encode_equals_the_sibling(golden, name):
     assert all(b <= a_ + 1e-6 for a_, b in zip([float(x.norm())] + norms[:-1], norms))
 
 
+def encoder_fixture(meta):
+    """Configurations and seeded weights of an encoder fixture (shared with the GPU test of the encode side)."""
+    import importlib
+    E = importlib.import_module("qwen3-tts_amd.encoder")
+    ecfg = E.EncoderConfig.from_dict(meta["encoder_config"])
+    cfg = q3.DecoderConfig.from_dict(meta["config"])
+    w = {**q3.synthetic_weights(cfg, seed=meta["weight_seeds"][0]), **E.synthetic_encoder_weights(ecfg, cfg.codebook_dim, seed=meta["weight_seeds"][1])}
+    s = float(sum(t.double().abs().sum().item() for t in w.values()))
+    assert abs(s - meta["weight_abs_sum"]) <= 1e-9 * abs(s), "seeded weight generator drifted from the fixture"
+    return ecfg, cfg, w
+
+
+@pytest.mark.parametrize("name", ["encoder_tiny", "encoder_wide"])
+def test_encode_side_equals_the_sibling(golden, name):
+    """The tokenizer's encode side (conv encoder with ELU residual blocks and strided convs, LayerNorm transformer, the
+    replicate-padded stride-2 conv, split-RVQ encode) against the sibling MimiModel's stored outputs: the embeddings it
+    quantises to fp32 rounding, its codes up to near-ties (a frame whose two nearest rows are closer than the summation
+    noise may fall either way; everything after it in that frame's residual chain then differs), at lengths that no stride
+    divides and one shorter than a frame."""
+    import encoder_oracle as eo
+    meta, a = golden(name)
+    ecfg, cfg, w = encoder_fixture(meta)
+    for L in meta["lengths"]:
+        audio = torch.from_numpy(a[f"audio_{L}"])
+        codes, emb = eo.encode(ecfg, cfg, w, audio)
+        assert codes.shape == (audio.shape[0], cfg.num_quantizers, ecfg.frames(L)) and codes.dtype == torch.int64
+        np.testing.assert_allclose(emb.numpy(), a[f"emb_{L}"], atol=2e-5, rtol=1e-4)
+        assert float((codes.numpy() == a[f"codes_{L}"]).mean()) >= 0.99
+
+
 def test_rvq_negative_zero_start():
     """The accumulator starts at +0.0, so a single row of -0.0 dequantises to +0.0."""
     table = torch.tensor([[-0.0, 1.0]], dtype=torch.float32)
