@@ -122,6 +122,35 @@ int q3c_rvq_dequant_f32(q3c_ctx* ctx, const int64_t* codes_dev, int32_t batch, i
 int q3c_rvq_encode(q3c_ctx* ctx, const float* emb_dev, int32_t batch, int32_t frames, int32_t in_dim, int64_t* codes_dev,
                    void* hip_stream);
 
+/* -- the tokenizer's ENCODE side: 24 kHz audio -> code frames -------------------------------------------------------
+ * Stands in for tokenizer.encode(ref_audio), which the reference reaches through create_voice_clone_prompt (server.py:228-232,
+ * 298-303) in its in-context voice-clone mode; its server keeps that mode off (x_vector_only_mode=True, server.py:221, 283)
+ * and the arithmetic lives in the absent qwen-tts package, so sizes, tensor names and arithmetic follow the Mimi encoder of
+ * the sibling (modeling_mimi.py: conv encoder :450-492, residual block :408-447, transformer :729-779, stride-2 conv
+ * :1197-1206, _encode_frame :1230-1263).  The speaker x-vector of the reference's default mode is another network of
+ * qwen-tts and is not covered.
+ *
+ * q3c_encoder_configure goes between q3c_create and q3c_finalize; the context then also needs the encoder's tensors
+ * ("encoder.layers.N...", "encoder_transformer.layers.N...", "downsample.conv.weight", the quantiser's two input_proj, and
+ * "encoder_rope.inv_freq" [head_dim / 2]).  ratios[] are the conv encoder's strides in the order it applies them. */
+typedef struct q3c_encoder_config {
+    int32_t struct_size;
+    int32_t num_filters, kernel_size, residual_kernel_size, compress, last_kernel_size;
+    int32_t num_ratios; int32_t ratios[Q3C_MAX_STAGES];
+    int32_t hidden_size, num_attention_heads, head_dim, intermediate_size, num_hidden_layers, sliding_window;
+    int32_t downsample_stride;        /* kernel = 2 * stride, replicate padding, no bias */
+    int32_t max_positions;            /* longest audio, in rows at the transformer's rate (samples / prod(ratios)) */
+    float norm_eps;
+} q3c_encoder_config;
+int q3c_encoder_configure(q3c_ctx* ctx, const q3c_encoder_config* cfg);
+/* frames = ceil over every stride in turn (each strided conv pads its input on the right to a whole stride, mimi :269-279) */
+int q3c_encode_frames(const q3c_ctx* ctx, int64_t samples, int64_t* frames);
+int q3c_encode_workspace_bytes(q3c_ctx* ctx, int32_t batch, int32_t samples, size_t* bytes);
+/* audio_dev [B][samples] fp32 (mono, every item the same length) -> codes_dev [B][Q][frames] int64; embeddings_dev (optional,
+ * [B][frames][hidden_size] fp32) receives what the quantiser encodes.  Asynchronous on the stream; workspace as q3c_forward. */
+int q3c_encode(q3c_ctx* ctx, const float* audio_dev, int32_t batch, int32_t samples, int64_t* codes_dev, float* embeddings_dev,
+               void* workspace, size_t workspace_bytes, void* hip_stream);
+
 /* Sticky device-side error word.  Synchronises the stream; if set, clears it and returns Q3C_ERR_CODES (a code index
  * outside [0, codebook_size): stands in for the IndexError torch's embedding raises) or Q3C_ERR_INVALID_ARGUMENT
  * (streaming: bad slot id, stream longer than max_positions). */

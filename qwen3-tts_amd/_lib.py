@@ -23,7 +23,7 @@ EXPORTS = ["q3c_create", "q3c_destroy", "q3c_last_error", "q3c_version", "q3c_lo
            "q3c_set_tap", "q3c_causal_conv1d", "q3c_causal_tconv1d", "q3c_snake_beta", "q3c_profile_enable",
            "q3c_profile_read", "q3c_stream_pool_create", "q3c_stream_pool_destroy", "q3c_stream_state_bytes",
            "q3c_stream_reset", "q3c_stream_workspace_bytes", "q3c_stream_push", "q3c_stream_push_graph", "q3c_residual_unit", "q3c_convnext_block",
-           "q3c_transformer", "q3c_wav_to_pcm16"]
+           "q3c_transformer", "q3c_wav_to_pcm16", "q3c_encoder_configure", "q3c_encode_frames", "q3c_encode_workspace_bytes", "q3c_encode"]
 
 
 class Q3cProfileEntry(C.Structure):
@@ -46,6 +46,36 @@ class Q3cConfig(C.Structure):
         ("max_positions", C.c_int32),
         ("rvq_eps", C.c_float), ("rms_norm_eps", C.c_float), ("convnext_eps", C.c_float), ("snake_eps", C.c_float),
     ]
+
+
+class Q3cEncoderConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32),
+        ("num_filters", C.c_int32), ("kernel_size", C.c_int32), ("residual_kernel_size", C.c_int32), ("compress", C.c_int32),
+        ("last_kernel_size", C.c_int32),
+        ("num_ratios", C.c_int32), ("ratios", C.c_int32 * Q3C_MAX_STAGES),
+        ("hidden_size", C.c_int32), ("num_attention_heads", C.c_int32), ("head_dim", C.c_int32), ("intermediate_size", C.c_int32),
+        ("num_hidden_layers", C.c_int32), ("sliding_window", C.c_int32),
+        ("downsample_stride", C.c_int32), ("max_positions", C.c_int32),
+        ("norm_eps", C.c_float),
+    ]
+
+
+def make_encoder_config(ecfg, max_positions: int) -> Q3cEncoderConfig:
+    """`ecfg`: qwen3_tts_amd.encoder.EncoderConfig; max_positions in rows at the encoder transformer's rate."""
+    if len(ecfg.ratios) > Q3C_MAX_STAGES:
+        raise ValueError(f"ratios has more than {Q3C_MAX_STAGES} entries")
+    c = Q3cEncoderConfig()
+    c.struct_size = C.sizeof(Q3cEncoderConfig)
+    for f in ("num_filters", "kernel_size", "residual_kernel_size", "compress", "last_kernel_size", "hidden_size", "num_attention_heads",
+              "head_dim", "intermediate_size", "num_hidden_layers", "sliding_window", "downsample_stride"):
+        setattr(c, f, int(getattr(ecfg, f)))
+    c.num_ratios = len(ecfg.ratios)
+    for i, v in enumerate(ecfg.ratios):
+        c.ratios[i] = int(v)
+    c.max_positions = int(max_positions)
+    c.norm_eps = float(ecfg.norm_eps)
+    return c
 
 
 class Q3cError(RuntimeError):
@@ -101,6 +131,10 @@ def load() -> C.CDLL:
     lib.q3c_stream_workspace_bytes.argtypes = [vp, i32, i32, C.POINTER(C.c_size_t)]
     lib.q3c_stream_push.argtypes = [vp, vp, i32, vp, i32, vp, vp, C.c_size_t, vp]
     lib.q3c_stream_push_graph.argtypes = [vp, vp, i32, vp, i32, vp, vp, C.c_size_t, vp]
+    lib.q3c_encoder_configure.argtypes = [vp, C.POINTER(Q3cEncoderConfig)]
+    lib.q3c_encode_frames.argtypes = [vp, C.c_int64, i64p]
+    lib.q3c_encode_workspace_bytes.argtypes = [vp, i32, i32, C.POINTER(C.c_size_t)]
+    lib.q3c_encode.argtypes = [vp, vp, i32, i32, vp, vp, vp, C.c_size_t, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("q3c_destroy", "q3c_last_error", "q3c_version", "q3c_stream_pool_destroy"):

@@ -29,7 +29,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "convgemm_impl.h"), os.path.join(HERE, "..", "include", "q3c.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "convgemm_impl.h"), os.path.join(CSRC, "encoder_impl.h"),
+               os.path.join(HERE, "..", "include", "q3c.h")]
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

@@ -78,6 +78,12 @@ hipError_t q3_launch_mean_embedding(const long long* codes, int B, int Q, int T,
 // y[b, m] = act(bias + sum_t P[b, m - (taps - 1) + t, t]) over the rows m - (taps - 1) + t >= 0: the one-channel causal conv
 // whose per-tap products a fused unit left in P ([B][M][8] fp32); act: Q3_ACT_NONE or Q3_ACT_CLAMP
 hipError_t q3_launch_tap_sum(const float* P, const float* bias, float* y, int B, int M, int taps, int act, hipStream_t s);
+// ---- the encode side's small kernels: first conv (one audio channel -> F, k taps, causal), ELU over [B][n_item] with item
+// strides in elements, LayerNorm with bias, replicate padding ----
+hipError_t q3_launch_audio_conv(const float* audio, const float* w /*[F][k]*/, const float* bias, void* y, int B, int L, int F, int k, int dtype, hipStream_t s);
+hipError_t q3_launch_elu(const void* x, void* y, int B, long long n_item, long long x_bstride, long long y_bstride, int dtype, hipStream_t s);
+hipError_t q3_launch_layernorm(const void* x, const float* w, const float* bias, void* y, long long rows, int H, float eps, int dtype, hipStream_t s);
+hipError_t q3_launch_replicate_pad(const void* x, void* y, int B, int L, int C, int left, int Lout, int dtype, hipStream_t s);
 hipError_t q3_launch_rmsnorm(const void* x, const float* w, void* y, long long rows, int H, float eps, int dtype, hipStream_t s);
 // `hist` carried rows sit in front of each item's L rows of x (0: rows before the sequence are zero padding)
 hipError_t q3_launch_dwconv_ln(const void* x, const float* w /*[7][C], tap-major*/, const float* b, const float* lnw, const float* lnb,

@@ -37,6 +37,19 @@ struct Block {
     Snake first_act_tiled;     // units[0].a1 repeated `rate` times: the transposed conv's columns are (phase, channel)
 };
 
+// the encode side (encoder_impl.h)
+struct EncStage { GemmW c3, c1, down; int r = 1, dim = 0; };
+struct EncLayer { float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *ls_attn, *ls_mlp; GemmW qkv, o, fc1, fc2; };
+struct EncoderState {
+    q3c_encoder_config cfg{};
+    bool configured = false, ready = false;
+    float *conv0_w = nullptr, *conv0_b = nullptr;     // first conv, fp32 [F][k] and [F]
+    std::vector<EncStage> stages;
+    GemmW last, ds;
+    std::vector<EncLayer> layers;
+    float *cos_t = nullptr, *sin_t = nullptr;
+};
+
 uint16_t f32_to_bf16(float f) {
     uint32_t u; std::memcpy(&u, &f, 4);
     if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
@@ -92,11 +105,14 @@ struct q3c_ctx {
     std::vector<hipEvent_t> event_pool;
 
     int total_upsample = 1, trim = 0;
+
+    EncoderState enc;                 // the tokenizer's encode side, when q3c_encoder_configure was called
 };
 
 namespace {
 
 int fail(const q3c_ctx* c, int code, const std::string& msg) { if (c) c->err = msg; return code; }
+int encoder_finalize(q3c_ctx* c);     // encoder_impl.h
 
 // Brackets one launch with events when profiling is on.
 struct ProfScope {
@@ -975,6 +991,7 @@ int q3c_finalize(q3c_ctx* c) {
             for (int t = 0; t < 7; ++t) p16[(size_t)t * ch + ci] = wf->data[(size_t)ci * 7 + t];
         TRY(upload_typed(c, p16, Q3_BF16, &c->conv_out_fold));
     }
+    if (c->enc.configured) TRY(encoder_finalize(c));
     HIPCHK(c, hipGetDevice(&c->device));
     {   // this device's copy of the static workspace (every GPU has its own, at its own address)
         void* sp = nullptr;
@@ -1544,3 +1561,5 @@ int q3c_wav_to_pcm16(const float* wav, int64_t samples, int16_t* pcm, void* stre
 }
 
 }  // extern "C"
+
+#include "encoder_impl.h"

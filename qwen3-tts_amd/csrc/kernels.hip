@@ -249,36 +249,36 @@ __global__ void __launch_bounds__(256) dwconv_ln_kernel(const T* __restrict__ x,
 // keys [max(0, q0 - W + 1), q0 + 31] and their values sit in LDS as fp32; one wave walks 8 queries:
 // lane = key for the scores (softmax by wave reductions, fp32), lane = dim for P.V.
 // ------------------------------------------------------------------------------------------------
-constexpr int ATT_QT = 32;
+constexpr int ATT_QT = 32;    // queries per block; the launcher halves it (down to 8) when a long window's keys would not fit the LDS
 constexpr int ATT_MAXC = 4;   // window <= 64 * ATT_MAXC
 
 template <typename T>
 __global__ void __launch_bounds__(256) swa_attention_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                             const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                             int Tn, int nh, int nkv, int d, int window, float scale, int hist,
-                                                            const int* __restrict__ pos0, int max_pos, Q3KvRing ring) {
+                                                            const int* __restrict__ pos0, int max_pos, Q3KvRing ring, int qt) {
     // An item has `hist` carried rows then its new rows (Tn rows in all); only the new rows are queries.  Row r is frame
     // pos0[b] - hist + r of its stream; rows of negative frame number do not exist yet.  The new rows are rows of `qkv`
     // (Tn - hist per item); the carried rows' keys and values are read where they live, in the slot's ring buffer inside
     // its state record: frame f sits at ring row f mod hist, as [K (nkv*d) | V (nkv*d)].
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_att[];
-    const int q0 = hist + blockIdx.x * ATT_QT;
+    const int q0 = hist + blockIdx.x * qt;
     const int h = blockIdx.y, b = blockIdx.z;
     const int shift = pos0 ? pos0[b] - hist : 0;
     const int r_min = max(0, -shift);
     const int hk = h / (nh / nkv);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int q_hi = min(q0 + ATT_QT, Tn) - 1;
+    const int q_hi = min(q0 + qt, Tn) - 1;
     const int k_lo = max(r_min, q0 - window + 1);
     const int nk = q_hi - k_lo + 1;
-    const int nkmax = ATT_QT + window - 1;
+    const int nkmax = qt + window - 1;
     const int ds = d + 4;                          // padded row stride: rows stay 16-byte aligned, and the 16 lanes a ds_read_b128
                                                    // serves together (lane = key) cover all 64 banks
     const int half = d >> 1;
     float* Ks = (float*)smem_att;
     float* Vs = Ks + (size_t)nkmax * ds;
     float* Qs = Vs + (size_t)nkmax * ds;
-    float* Ps = Qs + (size_t)ATT_QT * d + (size_t)wave * 4 * 64 * ATT_MAXC;     // four probability rows per wave
+    float* Ps = Qs + (size_t)qt * d + (size_t)wave * 4 * 64 * ATT_MAXC;     // four probability rows per wave
     const int rs = (nh + 2 * nkv) * d;             // qkv row stride
     const T* base = qkv + ((long long)b * (Tn - hist) - hist) * (long long)rs;       // row r >= hist of the item is qkv row r - hist
     const T* ring_base = nullptr;
@@ -450,6 +450,64 @@ __global__ void __launch_bounds__(256) swa_attention_kernel(const T* __restrict_
                 if (g0 + q < nq) out[((size_t)b * (Tn - hist) + (i0 + q - hist)) * (nh * d) + h * d + e] = q3_from_f32<T>(a[q]);
         }
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- the encode side's small kernels ---------------------------------------------------------------
+// First conv of the audio encoder: one input channel, k taps, causal zero padding; one thread per output element.
+template <typename T>
+__global__ void __launch_bounds__(256) audio_conv_kernel(const float* __restrict__ audio, const float* __restrict__ w, const float* __restrict__ bias,
+                                                         T* __restrict__ y, int L, int F, int k) {
+    const long long b = blockIdx.y;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)L * F) return;
+    const int t = (int)(i / F), f = (int)(i - (long long)t * F);
+    const float* a = audio + b * L;
+    float acc = bias[f];
+    for (int j = 0; j < k; ++j) {
+        const int tt = t - (k - 1) + j;
+        if (tt >= 0) acc = fmaf(w[f * k + j], a[tt], acc);
+    }
+    y[(b * L + t) * F + f] = q3_from_f32<T>(acc);
+}
+
+// ELU (alpha = 1) of [B][L][C] rows; source and destination may have different item strides (the destination of a strided
+// conv's input is padded to a whole number of strides) and may be the same tensor.
+template <typename T>
+__global__ void __launch_bounds__(256) elu_kernel(const T* __restrict__ x, T* __restrict__ y, long long n_item, long long x_bstride, long long y_bstride) {
+    const long long b = blockIdx.y;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_item; i += (long long)gridDim.x * 256) {
+        const float v = q3_to_f32(x[b * x_bstride + i]);
+        y[b * y_bstride + i] = q3_from_f32<T>(v > 0.f ? v : expm1f(v));
+    }
+}
+
+// LayerNorm with bias over rows of H elements: one wave per row, statistics in fp32 (mean, then the centred second moment).
+template <typename T>
+__global__ void __launch_bounds__(256) layernorm_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                        T* __restrict__ y, long long rows, int H, float eps) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const T* xr = x + row * H;
+    float s = 0.f;
+    for (int c = lane; c < H; c += 64) s += q3_to_f32(xr[c]);
+    const float mean = wave_sum(s) / (float)H;
+    float q = 0.f;
+    for (int c = lane; c < H; c += 64) { const float d = q3_to_f32(xr[c]) - mean; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+    for (int c = lane; c < H; c += 64) y[row * H + c] = q3_from_f32<T>((q3_to_f32(xr[c]) - mean) * rstd * w[c] + bias[c]);
+}
+
+// y[b][i] = x[b][clamp(i - left, 0, L - 1)] for i < Lout: replicate padding of a [B][L][C] tensor on both sides
+template <typename T>
+__global__ void __launch_bounds__(256) replicate_pad_kernel(const T* __restrict__ x, T* __restrict__ y, int L, int C, int left, int Lout) {
+    const long long b = blockIdx.y;
+    const long long n = (long long)Lout * C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int r = (int)(i / C), c = (int)(i - (long long)r * C);
+        const int src = min(max(r - left, 0), L - 1);
+        y[b * n + i] = x[(b * L + src) * C + c];
     }
 }
 
@@ -938,21 +996,60 @@ hipError_t q3_launch_swa_attention(const void* qkv, void* out, const float* cos_
         return hipGetLastError();
     }
     if (window < 1 || window + 3 > 64 * ATT_MAXC || (d & 3) || d > 256) return hipErrorInvalidValue;    // rows are read 16 bytes at a time
-    const int nkmax = ATT_QT + window - 1;
-    size_t lds = ((size_t)2 * nkmax * (d + 4) + (size_t)ATT_QT * d + 4 * 4 * 64 * ATT_MAXC) * sizeof(float);
+    int qt = ATT_QT;
+    auto lds_for = [&](int q) { return ((size_t)2 * (q + window - 1) * (d + 4) + (size_t)q * d + 4 * 4 * 64 * ATT_MAXC) * sizeof(float); };
+    while (qt > 8 && lds_for(qt) > 160 * 1024) qt >>= 1;      // a long window (the encoder's 250 at head size 64): fewer queries per block
+    const size_t lds = lds_for(qt);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    dim3 grid((T + ATT_QT - 1) / ATT_QT, nh, B);
+    dim3 grid((T + qt - 1) / qt, nh, B);
     const float scale = 1.0f / sqrtf((float)d);
     hipError_t e;
     if (dtype == Q3_BF16) {
         auto k = swa_attention_kernel<bf16>;
         if (lds > 48 * 1024 && (e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const bf16*)qkv, (bf16*)out, cos_t, sin_t, hist + T, nh, nkv, d, window, scale, hist, pos0, max_pos, ring);
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const bf16*)qkv, (bf16*)out, cos_t, sin_t, hist + T, nh, nkv, d, window, scale, hist, pos0, max_pos, ring, qt);
     } else {
         auto k = swa_attention_kernel<float>;
         if (lds > 48 * 1024 && (e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const float*)qkv, (float*)out, cos_t, sin_t, hist + T, nh, nkv, d, window, scale, hist, pos0, max_pos, ring);
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const float*)qkv, (float*)out, cos_t, sin_t, hist + T, nh, nkv, d, window, scale, hist, pos0, max_pos, ring, qt);
     }
+    return hipGetLastError();
+}
+
+hipError_t q3_launch_audio_conv(const float* audio, const float* w, const float* bias, void* y, int B, int L, int F, int k, int dtype, hipStream_t s) {
+    if (B == 0 || L == 0) return hipSuccess;
+    if (B > 65535 || F < 1 || k < 1) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)(((long long)L * F + 255) / 256), B);
+    if (dtype == Q3_BF16) hipLaunchKernelGGL(audio_conv_kernel<bf16>, grid, dim3(256), 0, s, audio, w, bias, (bf16*)y, L, F, k);
+    else hipLaunchKernelGGL(audio_conv_kernel<float>, grid, dim3(256), 0, s, audio, w, bias, (float*)y, L, F, k);
+    return hipGetLastError();
+}
+
+hipError_t q3_launch_elu(const void* x, void* y, int B, long long n_item, long long x_bstride, long long y_bstride, int dtype, hipStream_t s) {
+    if (B == 0 || n_item == 0) return hipSuccess;
+    if (B > 65535) return hipErrorInvalidValue;
+    const long long blocks = (n_item + 255) / 256;
+    const dim3 grid((unsigned)(blocks > 8192 ? 8192 : blocks), B);
+    if (dtype == Q3_BF16) hipLaunchKernelGGL(elu_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)x, (bf16*)y, n_item, x_bstride, y_bstride);
+    else hipLaunchKernelGGL(elu_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (float*)y, n_item, x_bstride, y_bstride);
+    return hipGetLastError();
+}
+
+hipError_t q3_launch_layernorm(const void* x, const float* w, const float* bias, void* y, long long rows, int H, float eps, int dtype, hipStream_t s) {
+    if (rows == 0) return hipSuccess;
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    if (dtype == Q3_BF16) hipLaunchKernelGGL(layernorm_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)x, w, bias, (bf16*)y, rows, H, eps);
+    else hipLaunchKernelGGL(layernorm_kernel<float>, grid, dim3(256), 0, s, (const float*)x, w, bias, (float*)y, rows, H, eps);
+    return hipGetLastError();
+}
+
+hipError_t q3_launch_replicate_pad(const void* x, void* y, int B, int L, int C, int left, int Lout, int dtype, hipStream_t s) {
+    if (B == 0 || Lout == 0) return hipSuccess;
+    if (B > 65535 || L < 1) return hipErrorInvalidValue;
+    const long long blocks = ((long long)Lout * C + 255) / 256;
+    const dim3 grid((unsigned)(blocks > 8192 ? 8192 : blocks), B);
+    if (dtype == Q3_BF16) hipLaunchKernelGGL(replicate_pad_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)x, (bf16*)y, L, C, left, Lout);
+    else hipLaunchKernelGGL(replicate_pad_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (float*)y, L, C, left, Lout);
     return hipGetLastError();
 }
 

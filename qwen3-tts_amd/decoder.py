@@ -93,7 +93,10 @@ class Decoder:
     """One decoder instance = one q3c context on one GPU."""
 
     def __init__(self, cfg: DecoderConfig, weights: Dict[str, torch.Tensor], device: Union[str, torch.device] = "cuda:0",
-                 precision: str = "bf16", max_positions: int = 8192, max_frames_per_launch: int = 64 * 325):
+                 precision: str = "bf16", max_positions: int = 8192, max_frames_per_launch: int = 64 * 325,
+                 encoder=None, encoder_max_positions: int = 16384):
+        """`encoder` (an `encoder.EncoderConfig`) adds the tokenizer's encode side to the context: `weights` must then hold
+        the encoder's tensors too (`encoder.encoder_param_specs`) and the quantiser's two `input_proj`."""
         if not torch.cuda.is_available():
             raise RuntimeError("qwen3_tts_amd.Decoder needs a ROCm GPU (MI355X); there is no CPU fallback")
         self.cfg = cfg
@@ -112,6 +115,12 @@ class Decoder:
             self._check(rc)
             w = dict(weights)
             w["rope.inv_freq"] = rope_inv_freq(cfg)
+            self.encoder_cfg = encoder
+            if encoder is not None:
+                ec = _lib.make_encoder_config(encoder, encoder_max_positions)
+                self._check(self._lib.q3c_encoder_configure(self._ctx, C.byref(ec)))
+                d = encoder.head_dim
+                w["encoder_rope.inv_freq"] = 1.0 / (encoder.rope_theta ** (torch.arange(0, d, 2, dtype=torch.float) / d))
             for name, t in w.items():
                 t = t.detach().to(device="cpu", dtype=torch.float32).contiguous()
                 shape = (C.c_int64 * t.dim())(*t.shape)
@@ -276,6 +285,34 @@ class Decoder:
         return codes
 
     # ------------------------------------------------------------------------------------------------
+    def encode(self, audio: torch.Tensor, return_embeddings: bool = False):
+        """The tokenizer's encode side: mono 24 kHz audio [B, L] (or [B, 1, L]) -> codes [B, Q, frames] int64 on the device,
+        frames = `encoder_cfg.frames(L)` (reference server.py:228-232 reaches it through create_voice_clone_prompt; arithmetic
+        of the sibling MimiModel.encode).  With return_embeddings also what the quantiser encoded, [B, frames, hidden] fp32."""
+        if self.encoder_cfg is None:
+            raise RuntimeError("this Decoder was built without an encoder configuration")
+        a = audio.to(self.device, torch.float32)
+        if a.dim() == 3:
+            if a.shape[1] != 1:
+                raise ValueError(f"Expected mono audio [B, 1, L], got {tuple(a.shape)}")
+            a = a[:, 0]
+        if a.dim() != 2 or a.shape[1] < 1:
+            raise ValueError(f"Expected audio of shape [B, L], got {tuple(audio.shape)}")
+        a = a.contiguous()
+        B, L = a.shape
+        T = self.encoder_cfg.frames(L)
+        codes = torch.empty((B, self.cfg.num_quantizers, T), dtype=torch.int64, device=self.device)
+        emb = torch.empty((B, T, self.encoder_cfg.hidden_size), dtype=torch.float32, device=self.device) if return_embeddings else None
+        with torch.cuda.device(self.device):
+            need = C.c_size_t()
+            self._check(self._lib.q3c_encode_workspace_bytes(self._ctx, B, L, C.byref(need)))
+            ws = torch.empty(need.value + 256, dtype=torch.uint8, device=self.device)
+            base = (ws.data_ptr() + 255) // 256 * 256
+            self._check(self._lib.q3c_encode(self._ctx, C.c_void_p(a.data_ptr()), B, L, C.c_void_p(codes.data_ptr()),
+                                             C.c_void_p(emb.data_ptr()) if emb is not None else None, C.c_void_p(base), need.value,
+                                             self._stream()))
+        return (codes, emb) if return_embeddings else codes
+
     def _normalize_items(self, encoded: CodesLike) -> List[torch.Tensor]:
         """Accepts a [T, Q] / [Q, T] matrix, a [B, T, Q] / [B, Q, T] tensor, {"audio_codes": ...}, or a list of
         those; returns per-utterance [Q, T_i] int64 tensors."""
