@@ -454,31 +454,53 @@ __global__ void __launch_bounds__(256) swa_attention_kernel(const T* __restrict_
 }
 
 // ---- the encode side's small kernels ---------------------------------------------------------------
-// First conv of the audio encoder: one input channel, k taps, causal zero padding; one thread per output element.
+// First conv of the audio encoder: one input channel, k taps, causal zero padding.  A thread produces eight consecutive
+// channels of one sample (a 16-byte store in bf16); the F x k weights and the bias sit in LDS.
 template <typename T>
 __global__ void __launch_bounds__(256) audio_conv_kernel(const float* __restrict__ audio, const float* __restrict__ w, const float* __restrict__ bias,
                                                          T* __restrict__ y, int L, int F, int k) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_enc[];
+    float* ws = (float*)smem_enc;                    // [F][k] then [F]
+    for (int i = threadIdx.x; i < F * k; i += 256) ws[i] = w[i];
+    for (int i = threadIdx.x; i < F; i += 256) ws[F * k + i] = bias[i];
+    __syncthreads();
     const long long b = blockIdx.y;
+    const int g8 = F >> 3;                           // channel groups per sample
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long long)L * F) return;
-    const int t = (int)(i / F), f = (int)(i - (long long)t * F);
+    if (i >= (long long)L * g8) return;
+    const int t = (int)(i / g8), f0 = (int)(i - (long long)t * g8) * 8;
     const float* a = audio + b * L;
-    float acc = bias[f];
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = ws[F * k + f0 + u];
     for (int j = 0; j < k; ++j) {
         const int tt = t - (k - 1) + j;
-        if (tt >= 0) acc = fmaf(w[f * k + j], a[tt], acc);
+        if (tt < 0) continue;
+        const float av = a[tt];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] = fmaf(ws[(f0 + u) * k + j], av, acc[u]);
     }
-    y[(b * L + t) * F + f] = q3_from_f32<T>(acc);
+    T* dst = y + (b * L + t) * F + f0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) dst[u] = q3_from_f32<T>(acc[u]);
 }
 
-// ELU (alpha = 1) of [B][L][C] rows; source and destination may have different item strides (the destination of a strided
-// conv's input is padded to a whole number of strides) and may be the same tensor.
+// ELU (alpha = 1) of [B][n_item] elements, 16 bytes per thread and step; source and destination may have different item
+// strides (the destination of a strided conv's input is padded to a whole number of strides) and may be the same tensor.
 template <typename T>
 __global__ void __launch_bounds__(256) elu_kernel(const T* __restrict__ x, T* __restrict__ y, long long n_item, long long x_bstride, long long y_bstride) {
+    constexpr int EPV = 16 / (int)sizeof(T);
     const long long b = blockIdx.y;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_item; i += (long long)gridDim.x * 256) {
-        const float v = q3_to_f32(x[b * x_bstride + i]);
-        y[b * y_bstride + i] = q3_from_f32<T>(v > 0.f ? v : expm1f(v));
+    const long long nv = n_item / EPV;               // the launcher checks that items and strides are whole 16-byte pieces
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
+        uint4 v = *(const uint4*)(x + b * x_bstride + i * EPV);
+        T* e = (T*)&v;
+#pragma unroll
+        for (int u = 0; u < EPV; ++u) {
+            const float f = q3_to_f32(e[u]);
+            e[u] = q3_from_f32<T>(f > 0.f ? f : expm1f(f));
+        }
+        *(uint4*)(y + b * y_bstride + i * EPV) = v;
     }
 }
 
@@ -543,7 +565,7 @@ __global__ void __launch_bounds__(256) tap_sum_kernel(const float* __restrict__ 
 // LDS).  Its A operand, V^T, is read from the row-major value image by transposed LDS reads (four keys x one dimension per
 // lane and read).  Rotated queries and keys and the probabilities are rounded to bf16 (operands of the matrix cores): the
 // same roundings a bf16 run of the reference's attention makes.
-constexpr int AM_QB = 128, AM_KR = 224, AM_D = 64;
+constexpr int AM_QB = 128, AM_D = 64;     // NKT key tiles of 32 per wave: windows up to 32 (NKT - 1) + 1 (4: the decoder's 72; 9: the encoder's 250)
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned am_pack2(float a, float b) {
@@ -571,20 +593,22 @@ __device__ __forceinline__ void am_rope8(const uint4& lo, const uint4& hi, const
 __device__ __forceinline__ int am_off_k(int row, int ch) { return 128 * row + 16 * (ch ^ ((row >> 1) & 7)); }
 __device__ __forceinline__ int am_off_v(int row, int ch) { return 128 * row + 16 * (ch ^ (((row >> 1) & 1) << 2)); }
 
+template <int NKT>
 __global__ void __launch_bounds__(256) swa_attention_mfma_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                                  const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                                  int Tn, int nh, int nkv, int window, float scale, int max_pos) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_att[];
     unsigned char* Ki = smem_att;
+    constexpr int AM_KR = AM_QB + 32 * (NKT - 1);       // key rows a block stages
     unsigned char* Vi = smem_att + AM_KR * 128;
     const int q0 = blockIdx.x * AM_QB, h = blockIdx.y, b = blockIdx.z;
     const int hk = h / (nh / nkv);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rs = (nh + 2 * nkv) * AM_D;
     const bf16* base = qkv + (size_t)b * Tn * rs;
-    const int k_lo = q0 - 96;                                   // key of image row 0; wave w reads rows 32w .. 32w + 127
+    const int k_lo = q0 - 32 * (NKT - 1);                       // key of image row 0; wave w reads rows 32 w .. 32 (w + NKT) - 1
     const int waves_on = min(4, (Tn - q0 + 31) >> 5);
-    const int rows = 96 + 32 * waves_on;
+    const int rows = 32 * (NKT - 1) + 32 * waves_on;
     for (int i = tid; i < rows * 4; i += 256) {                 // keys: one (row, 8-dimension group and its partner) per thread
         const int r = i >> 2, g = i & 3, pos = k_lo + r;
         uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
@@ -623,9 +647,9 @@ __global__ void __launch_bounds__(256) swa_attention_mfma_kernel(const bf16* __r
         }
     }
     const int krow0 = 32 * wave;
-    f32x16 sacc[4];
+    f32x16 sacc[NKT];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < NKT; ++t) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) sacc[t][i] = 0.f;
         const int row = krow0 + 32 * t + r;
@@ -639,7 +663,7 @@ __global__ void __launch_bounds__(256) swa_attention_mfma_kernel(const bf16* __r
     const int key_min = max(0, qi - window + 1);
     float m = -INFINITY;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < NKT; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int kpos = k_lo + krow0 + 32 * t + 8 * (i >> 2) + 4 * hh + (i & 3);
@@ -649,9 +673,9 @@ __global__ void __launch_bounds__(256) swa_attention_mfma_kernel(const bf16* __r
         }
     m = fmaxf(m, __shfl_xor(m, 32));
     float sum = 0.f;
-    bf16x8 pf[4][2];
+    bf16x8 pf[NKT][2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < NKT; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const float pv = __expf(sacc[t][i] - m);
@@ -667,7 +691,7 @@ __global__ void __launch_bounds__(256) swa_attention_mfma_kernel(const bf16* __r
         for (int i = 0; i < 16; ++i) oacc[n][i] = 0.f;
     const int q4 = (lane >> 2) & 3, p4 = lane & 3, c16 = (lane >> 4) & 1;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < NKT; ++t)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -986,9 +1010,10 @@ hipError_t q3_launch_swa_attention(const void* qkv, void* out, const float* cos_
                                d, window, scale1, hist, pos0, max_pos, ring);
         return hipGetLastError();
     }
-    if (dtype == Q3_BF16 && d == AM_D && hist == 0 && !pos0 && window >= 1 && window <= 97 && nkv > 0 && nh % nkv == 0 && !(q3_convgemm_tuning & 256)) {
-        const size_t ldsm = (size_t)2 * AM_KR * 128;
-        auto km = swa_attention_mfma_kernel;
+    if (dtype == Q3_BF16 && d == AM_D && hist == 0 && !pos0 && window >= 1 && window <= 257 && nkv > 0 && nh % nkv == 0 && !(q3_convgemm_tuning & 256)) {
+        const bool wide = window > 97;             // nine key tiles per wave instead of four
+        const size_t ldsm = (size_t)2 * (AM_QB + 32 * (wide ? 8 : 3)) * 128;
+        auto km = wide ? swa_attention_mfma_kernel<9> : swa_attention_mfma_kernel<4>;
         hipError_t em = hipFuncSetAttribute((const void*)km, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm);
         if (em != hipSuccess) return em;
         dim3 gridm((T + AM_QB - 1) / AM_QB, nh, B);
@@ -1018,18 +1043,20 @@ hipError_t q3_launch_swa_attention(const void* qkv, void* out, const float* cos_
 
 hipError_t q3_launch_audio_conv(const float* audio, const float* w, const float* bias, void* y, int B, int L, int F, int k, int dtype, hipStream_t s) {
     if (B == 0 || L == 0) return hipSuccess;
-    if (B > 65535 || F < 1 || k < 1) return hipErrorInvalidValue;
-    const dim3 grid((unsigned)(((long long)L * F + 255) / 256), B);
-    if (dtype == Q3_BF16) hipLaunchKernelGGL(audio_conv_kernel<bf16>, grid, dim3(256), 0, s, audio, w, bias, (bf16*)y, L, F, k);
-    else hipLaunchKernelGGL(audio_conv_kernel<float>, grid, dim3(256), 0, s, audio, w, bias, (float*)y, L, F, k);
+    if (B > 65535 || F < 8 || (F & 7) || k < 1 || (size_t)F * (k + 1) * 4 > 48 * 1024) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)(((long long)L * (F / 8) + 255) / 256), B);
+    const size_t lds = (size_t)F * (k + 1) * 4;
+    if (dtype == Q3_BF16) hipLaunchKernelGGL(audio_conv_kernel<bf16>, grid, dim3(256), lds, s, audio, w, bias, (bf16*)y, L, F, k);
+    else hipLaunchKernelGGL(audio_conv_kernel<float>, grid, dim3(256), lds, s, audio, w, bias, (float*)y, L, F, k);
     return hipGetLastError();
 }
 
 hipError_t q3_launch_elu(const void* x, void* y, int B, long long n_item, long long x_bstride, long long y_bstride, int dtype, hipStream_t s) {
     if (B == 0 || n_item == 0) return hipSuccess;
-    if (B > 65535) return hipErrorInvalidValue;
-    const long long blocks = (n_item + 255) / 256;
-    const dim3 grid((unsigned)(blocks > 8192 ? 8192 : blocks), B);
+    const int epv = dtype == Q3_BF16 ? 8 : 4;
+    if (B > 65535 || n_item % epv || x_bstride % epv || y_bstride % epv || ((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return hipErrorInvalidValue;
+    const long long blocks = (n_item / epv + 255) / 256;
+    const dim3 grid((unsigned)(blocks > 16384 ? 16384 : blocks), B);
     if (dtype == Q3_BF16) hipLaunchKernelGGL(elu_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)x, (bf16*)y, n_item, x_bstride, y_bstride);
     else hipLaunchKernelGGL(elu_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (float*)y, n_item, x_bstride, y_bstride);
     return hipGetLastError();

@@ -66,6 +66,18 @@ def test_encode_at_mimi_sizes_vs_oracle():
     agree16 = float((codes16.cpu() == want_codes).float().mean())
     print(f"mimi-size encoder bf16: embeddings {snr:.1f} dB, codes equal {100 * agree16:.1f} % (first layer {100 * float((codes16.cpu()[:, 0] == want_codes[:, 0]).float().mean()):.1f} %)")
     assert snr >= 30.0 and agree16 >= 0.5
+    # bf16 runs the window-250 attention on the matrix cores (nine key tiles per wave); the vector-ALU kernel (the library's
+    # measurement switch) must land at the same distance from the oracle
+    from qwen3_tts_amd import _lib
+    lib = _lib.load()
+    try:
+        lib.q3c_debug_set_tuning(256)
+        _, emb_v = dec16.encode(audio, return_embeddings=True)
+    finally:
+        lib.q3c_debug_set_tuning(0)
+    snr_v = snr_db(want_emb, emb_v.cpu().numpy())
+    print(f"mimi-size encoder bf16, vector-ALU attention: embeddings {snr_v:.1f} dB; between the two kernels {snr_db(emb_v.cpu().numpy(), emb16.cpu().numpy()):.1f} dB")
+    assert snr_v >= 30.0 and abs(snr_v - snr) <= 3.0
 
 
 def test_encode_argument_errors(golden):
