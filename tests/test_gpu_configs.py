@@ -90,6 +90,51 @@ def test_flagship_transformer_bf16_both_attention_kernels_vs_oracle(flagship, fl
     print(f"transformer bf16 T={T}: " + ", ".join(f"{k} {snr_db(want, v):.1f} dB" for k, v in got.items()))
 
 
+@pytest.mark.parametrize("window,kv_heads", [(72, 2), (40, 4), (97, 1), (250, 2)])
+def test_matrix_core_attention_grouped_heads_and_windows_vs_oracle(window, kv_heads):
+    """Head size 64 with grouped key / value heads and windows on both sides of the four-tile limit (97) and at the nine-tile
+    kernel's 250, two layers, bf16: the whole small decode's transformer stage against the oracle, both attention kernels."""
+    cfg = q3.tiny_config(hidden_size=256, latent_dim=64, num_attention_heads=4, num_key_value_heads=kv_heads, head_dim=64,
+                         intermediate_size=256, sliding_window=window)
+    w = q3.synthetic_weights(cfg, seed=21)
+    dec = Decoder(cfg, w, device="cuda:0", precision="bf16")
+    T = 300 if window > 97 else 150
+    x = torch.randn(2, T, cfg.latent_dim, generator=torch.Generator().manual_seed(window))
+    want = oracle.transformer(cfg, x, w).numpy()
+    lib = _lib.load()
+    got = {}
+    try:
+        for name, bits in (("matrix cores", 0), ("vector ALU", 256)):
+            lib.q3c_debug_set_tuning(bits)
+            got[name] = dec.transformer(x).cpu().numpy()
+    finally:
+        lib.q3c_debug_set_tuning(0)
+    print(f"window {window}, {kv_heads} kv heads: " + ", ".join(f"{k} {snr_db(want, v):.1f} dB" for k, v in got.items()))
+    for name, y in got.items():
+        assert np.isfinite(y).all() and snr_db(want, y) >= 38.0, (name, snr_db(want, y))
+    assert not np.array_equal(got["matrix cores"], got["vector ALU"])          # the switch really selects another kernel
+
+
+def test_final_conv_fold_at_32_channels():
+    """The fold on the 256 x 32 fused shape (a decoder whose last block has 32 channels): equal to the separate launch."""
+    cfg = q3.tiny_config(decoder_dim=512)
+    dec = Decoder(cfg, q3.synthetic_weights(cfg, seed=4), device="cuda:0", precision="bf16")
+    codes = q3.random_codes(cfg, 2, 40, seed=6).cuda()
+    lib = _lib.load()
+    try:
+        lib.q3c_debug_set_tuning(512)
+        want = dec.forward(codes).cpu().numpy()
+    finally:
+        lib.q3c_debug_set_tuning(0)
+    got = dec.forward(codes).cpu().numpy()
+    assert np.isfinite(got).all() and max_abs(want, got) <= 2e-6, max_abs(want, got)
+    dec.profile(True, detail=True)
+    dec.forward(codes)
+    names = [p["kernel"] for p in dec.profile_read()]
+    dec.profile(False)
+    assert "tap_sum" in names, names                                          # the folded path is the one that ran
+
+
 def test_final_conv_folded_into_the_last_unit_equals_its_own_launch(flagship, flagship_bf16):
     """The bulk bf16 decode never stores the last residual unit's output: its epilogue leaves the final conv's per-tap products
     (8 floats per row) and a diagonal-sum kernel finishes the conv.  Same bf16 inputs to the conv's products, fp32 sums in
