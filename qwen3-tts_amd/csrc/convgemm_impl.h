@@ -786,7 +786,10 @@ convgemm_kernel(const ConvGemmArgs p) {
     // the stores, and wait for everything.  It therefore does not know that they are pending; an explicit s_waitcnt vmcnt(N) is the wait,
     // N = the vector-memory operations issued since (the pass's stores, unconditional in this path).
     u32x4 rpre[NPIECE];
-    auto r_fetch_full = [&](int pass) {
+    // second set of rows in flight, for the fused unit's late residual add (below): there the rows of pass p are consumed at
+    // the END of pass p, so the request for pass p + 1 needs registers of its own to be a whole pass ahead
+    u32x4 rpre2[FUSE2 ? NPIECE : 1];
+    auto r_fetch_into = [&](int pass, u32x4* dst) {
         const int rh = pass & 1, q = pass >> 1, jgi = q % (WN / JG), i = q / (WN / JG);
 #pragma unroll
         for (int k = 0; k < NPIECE; ++k) {
@@ -794,13 +797,15 @@ convgemm_kernel(const ConvGemmArgs p) {
             const int row = id / CPRW_F, ch = id - row * CPRW_F;
             const int m = m0 + wm * 32 * WM + i * 32 + rh * 16 + row;
             const int n = n0 + wn * 32 * WN + jgi * JG * 32 + ch * EPO;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rpre[k]) : "v"(Rb + (long long)m * p.ldr + n) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[k]) : "v"(Rb + (long long)m * p.ldr + n) : "memory");
         }
     };
-    auto r_pin = [&]() {                                         // after the wait: uses of the rows stay behind it
+    auto r_fetch_full = [&](int pass) { r_fetch_into(pass, rpre); };
+    auto r_pin_buf = [&](u32x4* buf) {                           // after the wait: uses of the rows stay behind it
 #pragma unroll
-        for (int k = 0; k < NPIECE; ++k) asm volatile("" : "+v"(rpre[k]));
+        for (int k = 0; k < NPIECE; ++k) asm volatile("" : "+v"(buf[k]));
     };
+    auto r_pin = [&]() { r_pin_buf(rpre); };
     auto r_fetch = [&](int pass, u32x4* dst) {                  // pass = (i * (WN / JG) + jg / JG) * 2 + rh
         const int rh = pass & 1, q = pass >> 1, jgi = q % (WN / JG), i = q / (WN / JG);
 #pragma unroll
@@ -934,9 +939,14 @@ convgemm_kernel(const ConvGemmArgs p) {
             if (lane < 32 && row_ok) *(f32x4*)(Pb + (long long)(mrow0 + (lane & 15)) * 8 + 4 * (lane >> 4)) = pacc;
         }
     };
-    auto fast_epilogue = [&](auto dual_tag, auto fold_tag) {
+    // LATE (fused unit, nothing non-linear after the residual add, one output): the residual rows skip the slab.  Phase 1
+    // leaves acc + bias in the slab and phase 2, which reads it row-wise anyway, adds the rows straight from the registers
+    // they were loaded into (the same fp32 add on the same operands: bit-identical results): no residual -> slab writes,
+    // no per-element residual reads.  Rows of pass p + 1 are requested at the start of pass p into the other register set.
+    auto fast_epilogue = [&](auto dual_tag, auto fold_tag, auto late_tag) {
         constexpr bool DUAL = decltype(dual_tag)::value;
         constexpr bool FOLD = decltype(fold_tag)::value;
+        constexpr bool LATE = decltype(late_tag)::value;
         if (!FUSE2 && has_res) r_fetch_full(0);
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
@@ -946,7 +956,11 @@ convgemm_kernel(const ConvGemmArgs p) {
                 for (int rh = 0; rh < 2; ++rh) {
                     const int pidx = (i * (WN / JG) + jg / JG) * 2 + rh;
                     const int mrow0 = m0 + wm * 32 * WM + i * 32 + rh * 16, ncol0 = n0 + wn * 32 * WN + jg * 32;
-                    if (has_res) {
+                    u32x4* const rcur = (LATE && (pidx & 1)) ? rpre2 : rpre;
+                    if constexpr (LATE) {
+                        if (pidx + 1 < NPASS) r_fetch_into(pidx + 1, (pidx & 1) ? rpre : rpre2);
+                    }
+                    if (has_res && !LATE) {
                         // since the request: this tile's earlier work and waits (first pass) or one pass's stores
                         if (pidx == 0) wait_vmcnt_c<0>();
                         else wait_vmcnt_c<FOLD ? 1 : NPIECE * (DUAL ? 2 : 1)>();
@@ -973,7 +987,7 @@ convgemm_kernel(const ConvGemmArgs p) {
                         float* sa = slabA + (4 * half) * SLD + cl;
                         float* sb = slabB + (4 * half) * SLD + cl;
                         float vv[8], rr[8];
-                        if (has_res) {
+                        if (has_res && !LATE) {
 #pragma unroll
                             for (int r8 = 0; r8 < 8; ++r8) rr[r8] = sa[((r8 & 3) + 8 * (r8 >> 2)) * SLD];
                         }
@@ -984,7 +998,7 @@ convgemm_kernel(const ConvGemmArgs p) {
                             else if (first_act == Q3_ACT_SNAKE) v = q3_snake<TO>(v, ea, eib);
                             else if (first_act == Q3_ACT_CLAMP) v = fminf(1.0f, fmaxf(-1.0f, v));
                             if (!FUSE2) v *= sc;
-                            if (has_res) v += rr[r8];
+                            if (has_res && !LATE) v += rr[r8];
                             vv[r8] = v;
                         }
                         if (DUAL) {
@@ -1003,6 +1017,13 @@ convgemm_kernel(const ConvGemmArgs p) {
                     }
                     __builtin_amdgcn_wave_barrier();
                     if constexpr (FOLD) fold_pass(mrow0, true);
+                    if constexpr (LATE) {
+                        // rows of this pass: requested a pass ago; issued since: the last pass's stores and the next pass's request
+                        if (pidx == 0) wait_vmcnt_c<(NPASS > 1 ? NPIECE : 0)>();
+                        else if (pidx + 1 < NPASS) wait_vmcnt_c<2 * NPIECE>();
+                        else wait_vmcnt_c<NPIECE>();
+                        r_pin_buf(rcur);
+                    }
 #pragma unroll
                     for (int k = 0; k < (FOLD ? 0 : NPIECE); ++k) {
                         const int id = lane + 64 * k;
@@ -1013,9 +1034,15 @@ convgemm_kernel(const ConvGemmArgs p) {
                             const float* sp = (which ? slabB : slabA) + row * SLD + ch * EPO;
                             uint4 outv;
                             TO* oo = (TO*)&outv;
+                            const u32x4 rraw = rcur[k];
+                            const TO* rres = (const TO*)&rraw;
 #pragma unroll
                             for (int e = 0; e < EPO; e += 4) {
-                                const float4 t4 = *(const float4*)(sp + e);
+                                float4 t4 = *(const float4*)(sp + e);
+                                if constexpr (LATE) {
+                                    t4.x += q3_to_f32(rres[e]); t4.y += q3_to_f32(rres[e + 1]);
+                                    t4.z += q3_to_f32(rres[e + 2]); t4.w += q3_to_f32(rres[e + 3]);
+                                }
                                 oo[e] = q3_from_f32<TO>(t4.x); oo[e + 1] = q3_from_f32<TO>(t4.y);
                                 oo[e + 2] = q3_from_f32<TO>(t4.z); oo[e + 3] = q3_from_f32<TO>(t4.w);
                             }
@@ -1029,9 +1056,13 @@ convgemm_kernel(const ConvGemmArgs p) {
     };
     if (full) {
         if constexpr (FOLD_OK) {
-            if (fold) { fast_epilogue(std::false_type{}, std::true_type{}); mark(5); return; }
+            if (fold) { fast_epilogue(std::false_type{}, std::true_type{}, std::false_type{}); mark(5); return; }
         }
-        if (Y2b) fast_epilogue(std::true_type{}, std::false_type{}); else fast_epilogue(std::false_type{}, std::false_type{});
+        if constexpr (FUSE2) {
+            if (!Y2b && !has_post && !(p.debug & 128)) { fast_epilogue(std::false_type{}, std::false_type{}, std::true_type{}); mark(5); return; }
+        }
+        if (Y2b) fast_epilogue(std::true_type{}, std::false_type{}, std::false_type{});
+        else fast_epilogue(std::false_type{}, std::false_type{}, std::false_type{});
         mark(5);
         return;
     }
