@@ -36,14 +36,14 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_config_struct_matches_header():
-    src = '#include <stdio.h>\n#include "q3c.h"\nint main(void){printf("%zu %zu\\n", sizeof(q3c_config), sizeof(q3c_profile_entry));return 0;}\n'
+    src = '#include <stdio.h>\n#include "q3c.h"\nint main(void){printf("%zu %zu %zu\\n", sizeof(q3c_config), sizeof(q3c_profile_entry), sizeof(q3c_encoder_config));return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "t.c")
         open(c, "w").write(src)
         exe = os.path.join(d, "t")
         subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
-        a, b = map(int, subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split())
-    assert a == ctypes.sizeof(_lib.Q3cConfig) and b == ctypes.sizeof(_lib.Q3cProfileEntry)
+        a, b, e = map(int, subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split())
+    assert a == ctypes.sizeof(_lib.Q3cConfig) and b == ctypes.sizeof(_lib.Q3cProfileEntry) and e == ctypes.sizeof(_lib.Q3cEncoderConfig)
 
 
 def test_create_rejects_bad_config_without_gpu():
