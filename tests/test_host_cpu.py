@@ -58,6 +58,43 @@ def test_create_rejects_bad_config_without_gpu():
         _lib.make_config(q3.tiny_config(), "fp8", 512)
 
 
+def test_encoder_configuration_without_gpu():
+    """q3c_encoder_configure validates on the host; frame counts follow the chain of rounded-up strides of the conv encoder
+    (every strided conv pads its input on the right to a whole stride) and agree between Python, the C ABI and the oracle's
+    convolutions."""
+    import importlib
+    import sys
+    E = importlib.import_module("qwen3-tts_amd.encoder")
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import encoder_oracle as eo
+    lib = _lib.load()
+    ecfg = E.EncoderConfig()
+    assert ecfg.hop == 1920
+    ctx = ctypes.c_void_p()
+    cfg = _lib.make_config(q3.tiny_config(), "f32", 512)
+    assert lib.q3c_create(ctypes.byref(cfg), ctypes.byref(ctx)) == 0
+    ec = _lib.make_encoder_config(ecfg, 4096)
+    assert lib.q3c_encoder_configure(ctx, ctypes.byref(ec)) == 0
+    for samples in (1, 1919, 1920, 1921, 24000, 31337, 720000):
+        n = ctypes.c_int64()
+        assert lib.q3c_encode_frames(ctx, samples, ctypes.byref(n)) == 0
+        assert n.value == ecfg.frames(samples) >= -(-samples // ecfg.hop)
+    bad = _lib.make_encoder_config(ecfg, 4096)
+    bad.sliding_window = 400
+    assert lib.q3c_encoder_configure(ctx, ctypes.byref(bad)) == -7 and b"sliding_window" in lib.q3c_last_error(ctx)
+    bad = _lib.make_encoder_config(ecfg, 4096)
+    bad.hidden_size = 520
+    assert lib.q3c_encoder_configure(ctx, ctypes.byref(bad)) == -1
+    lib.q3c_destroy(ctx)
+    # the oracle's convolutions give the same lengths at the small sizes
+    t = E.tiny_encoder_config()
+    w = E.synthetic_encoder_weights(t, 8, seed=0)
+    for samples in (1, 5, 6, 7, 101):
+        x = eo.seanet_encoder(t, w, torch.zeros(1, 1, samples))
+        y = eo.causal_conv1d(x, w["downsample.conv.weight"], None, stride=t.downsample_stride, pad_mode="replicate")
+        assert y.shape[-1] == t.frames(samples), (samples, y.shape)
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
 def test_decoder_fails_loudly_without_gpu():
     from qwen3_tts_amd.decoder import Decoder
