@@ -338,6 +338,7 @@ def main() -> None:
     ap.add_argument("--streams", type=int, default=256)
     ap.add_argument("--push-frames", type=int, default=1)
     ap.add_argument("--no-graph", action="store_true", help="stream workload: plain launches instead of the HIP-graph replay")
+    ap.add_argument("--no-stream-record", action="store_true", help="skip the short streaming-latency record appended to the bulk line")
     ap.add_argument("--launch-check", action="store_true", help="every rank prints its rank / world size and exits (no GPU work)")
     args = ap.parse_args()
 
@@ -472,6 +473,13 @@ def main() -> None:
         if world == 1 and not args.no_cpu_baseline:
             threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
             out["cpu_baseline"] = cpu_baseline(cfg, weights, args.cpu_batch, frames, threads)
+        if world == 1 and not args.no_stream_record and not args.tiny:
+            # the streaming configuration (BASELINE.json configs[2]) beside the headline, outside its timed region: 256 streams
+            # x one frame per push, 100 pushes (a few seconds); the full measurement is `--workload stream`
+            sargs = argparse.Namespace(**{**vars(args), "steps": 100, "warmup": 10})
+            sb = stream_bench(sargs, cfg, weights, device)
+            out["streaming"] = {"streams": args.streams, "frames_per_push": args.push_frames, "pushes": 100,
+                                "p50_ms": sb["config"]["p50_ms"], "p99_ms": sb["config"]["p99_ms"], "audio_sec_per_sec": sb["value"]}
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
