@@ -69,7 +69,7 @@ hipError_t q3_launch_rvq_gather_sum(const long long* codes, int B, int Q, int T,
                                     const int* group_start_dev /*[G+1] first codebook of each group*/, int G,
                                     float* out /*[B,T,G,D]*/, int* err_flag, hipStream_t s);
 // the encode direction: embeddings [B][T][in_dim] fp32 -> codes [B][Q][T]; in_proj [G][D][in_dim] or null (then in_dim == D)
-// tables_t_dev: per code book a dimension-major copy [D/4][bins] of float4
+// tables_t_dev: per code book a dimension-major copy [D/4][bins] of float4, followed by the rows' squared norms [bins]
 hipError_t q3_launch_rvq_encode(const float* emb, int B, int T, int in_dim, int Q, int bins, int D, const float* const* tables_dev,
                                 const void* const* tables_t_dev, const int* group_start_dev, int G, const float* in_proj_dev,
                                 long long* codes, hipStream_t s);

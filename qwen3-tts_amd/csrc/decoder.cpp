@@ -73,7 +73,7 @@ struct q3c_ctx {
     float** tables_dev = nullptr;
     int* group_start_dev = nullptr;
     float* emb_table = nullptr;
-    void** tables_t_dev = nullptr;    // per code book a dimension-major copy [D/4][bins][4] (built when the encode weights are loaded)
+    void** tables_t_dev = nullptr;    // per code book a dimension-major copy [D/4][bins][4] followed by the rows' squared norms [bins]
     float* rvq_in_proj = nullptr;     // [G][codebook_dim][rvq_in_dim]: the groups' input_proj (encode direction), when loaded
     int rvq_in_dim = 0;
     GemmW rvq_proj, pre_conv, in_proj, out_proj;
@@ -847,10 +847,16 @@ int q3c_finalize(q3c_ctx* c) {
                 }
                 float* tp; TRY(upload_f32(c, tab, &tp));
                 c->tables.push_back(tp);
-                {   // the encode direction reads the table by dimension: [D/4][bins][4]
-                    std::vector<float> tt(tab.size());
-                    for (int r = 0; r < k.codebook_size; ++r)
-                        for (int d = 0; d < D; ++d) tt[((size_t)(d >> 2) * k.codebook_size + r) * 4 + (d & 3)] = tab[(size_t)r * D + d];
+                {   // the encode direction reads the table by dimension: [D/4][bins][4], then the rows' squared norms [bins]
+                    std::vector<float> tt(tab.size() + k.codebook_size);
+                    for (int r = 0; r < k.codebook_size; ++r) {
+                        double n2 = 0.0;
+                        for (int d = 0; d < D; ++d) {
+                            tt[((size_t)(d >> 2) * k.codebook_size + r) * 4 + (d & 3)] = tab[(size_t)r * D + d];
+                            n2 += (double)tab[(size_t)r * D + d] * tab[(size_t)r * D + d];
+                        }
+                        tt[tab.size() + r] = (float)n2;
+                    }
                     float* tpt; TRY(upload_f32(c, tt, &tpt));
                     tables_t.push_back(tpt);
                 }

@@ -142,6 +142,152 @@ __global__ void __launch_bounds__(256) rvq_encode_kernel(const float* __restrict
     }
 }
 
+// The same search on the fp32 matrix op, for code books of D dimensions and a multiple of 128 rows (the full-size 2048 x 256).
+// The nearest row minimises |c|^2 - 2 c.r (|r|^2 is common to all rows), and c.r for 32 rows x 32 frames is a 32 x 32 tile of
+// TABLE . RESIDUAL^T: v_mfma_f32_32x32x2_f32 with A = table[row][k] (from the dimension-major copy: one 16-byte load feeds two
+// k-steps), B = residual[frame][k] (held in registers for the whole layer, D / 2 per lane), |c|^2 from a table built with the
+// dimension-major copy.  Rows are accumulator rows, so a lane keeps the running minimum of ONE frame: compare in registers,
+// one exchange with lane ^ 32, then across the four waves, which split the rows.  Lowest index on ties, as argmin.
+constexpr int RVQM_FT = 32;
+
+template <int D>
+__global__ void __launch_bounds__(256) rvq_encode_mfma_kernel(const float* __restrict__ emb, long long frames, int T, int in_dim, int Q,
+                                                              int bins, const float* const* __restrict__ tables,
+                                                              const float4* const* __restrict__ tables_t /*[Q] x ([D/4][bins] float4, then [bins] |c|^2)*/,
+                                                              const int* __restrict__ group_start, int G,
+                                                              const float* __restrict__ in_proj, long long* __restrict__ codes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_rvq[];
+    constexpr int RLD = D + 1;                             // residual row stride: a wave's 32 frames on 32 banks
+    const int ELD = in_dim + 4;                            // embedding row stride (16-byte rows, spread over the banks)
+    float* E = (float*)smem_rvq;                           // [32][in_dim + 4]
+    float* R = E + (size_t)RVQM_FT * ELD;                  // [32][D + 1]
+    float* bd = R + (size_t)RVQM_FT * RLD;                 // [4 waves][32]
+    int* bi = (int*)(bd + 4 * RVQM_FT);
+    int* win = bi + 4 * RVQM_FT;                           // [32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr_l = lane & 31, hh = lane >> 5;
+    const long long f0 = (long long)blockIdx.x * RVQM_FT;
+    const int nf = (int)min((long long)RVQM_FT, frames - f0);
+    for (int i = tid; i < RVQM_FT * in_dim; i += 256) {
+        const int f = i / in_dim, e = i - f * in_dim;
+        E[f * ELD + e] = f < nf ? emb[(f0 + f) * in_dim + e] : 0.f;
+    }
+    __syncthreads();
+    const int bins_w = bins >> 2;                          // rows per wave
+    for (int g = 0; g < G; ++g) {
+        // residual <- input_proj_g(embedding) as W_g . E^T on the matrix op (rows = projection outputs, columns = frames; k-step
+        // (q, c) of lane half hh is input dimension 8 q + 4 hh + c for both operands), or the embedding itself
+        if (in_proj) {
+#pragma unroll 1
+            for (int t = 0; t < D / 128; ++t) {
+                const int j0 = wave * (D / 4) + 32 * t;
+                f32x16 acc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+                const float* wrow = in_proj + ((size_t)g * D + j0 + fr_l) * in_dim + 4 * hh;
+                const float* erow = E + fr_l * ELD + 4 * hh;
+#pragma unroll 4
+                for (int q8 = 0; q8 < (in_dim >> 3); ++q8) {
+                    const float4 a4 = *(const float4*)(wrow + 8 * q8);
+                    const float4 b4 = *(const float4*)(erow + 8 * q8);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) R[fr_l * RLD + j0 + (i & 3) + 8 * (i >> 2) + 4 * hh] = acc[i];
+            }
+        } else {
+            for (int i = tid; i < RVQM_FT * D; i += 256) {
+                const int f = i / D, j = i - f * D;
+                R[f * RLD + j] = E[f * ELD + j];
+            }
+        }
+        __syncthreads();
+        for (int q = group_start[g]; q < group_start[g + 1]; ++q) {
+            const float* tab = tables[q];
+            const float4* tt = tables_t[q];
+            const float* norms = (const float*)(tt + (size_t)(D >> 2) * bins);
+            // k-step s of lane half hh is dimension 8 (s / 4) + 4 hh + (s % 4): a lane then feeds four consecutive k-steps from
+            // ONE 16-byte piece of the dimension-major table and the two halves load different pieces
+            float breg[D / 2];                             // this lane's frame at those dimensions
+#pragma unroll
+            for (int s2 = 0; s2 < D / 2; ++s2) breg[s2] = R[fr_l * RLD + 8 * (s2 >> 2) + 4 * hh + (s2 & 3)];
+            float best = INFINITY;
+            int besti = 0x7fffffff;
+            // The table pieces of a tile are fetched eight at a time (32 k-steps), one group ahead of the group being multiplied,
+            // also across tiles; every index below is a compile-time constant so that breg stays in registers.
+            constexpr int NG = D / 64;                     // groups of eight 16-byte pieces (32 k-steps) per tile: D / 2 k-steps in all
+            float4 abuf[2][8];
+            const float4* ta0 = tt + (size_t)hh * bins + wave * bins_w + fr_l;      // piece 2 q8 + hh of row (tile base) + (lane & 31)
+            auto fetch = [&](float4* dst, const float4* ta, int grp) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dst[j] = ta[(size_t)(2 * (8 * grp + j)) * bins];
+            };
+            fetch(abuf[0], ta0, 0);
+            for (int bt = 0; bt < bins_w; bt += 32) {
+                const int bin0 = wave * bins_w + bt;
+                const float4* ta = ta0 + bt;
+                f32x16 acc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+                for (int grp = 0; grp < NG; ++grp) {
+                    if (grp + 1 < NG) fetch(abuf[(grp + 1) & 1], ta, grp + 1);
+                    else if (bt + 32 < bins_w) fetch(abuf[(grp + 1) & 1], ta + 32, 0);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float4 a4 = abuf[grp & 1][j];
+                        const int s0 = 4 * (8 * grp + j);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, breg[s0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, breg[s0 + 1], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, breg[s0 + 2], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, breg[s0 + 3], acc, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {           // accumulator i is row (i & 3) + 8 (i >> 2) + 4 hh of the tile
+                    const float4 n4 = *(const float4*)(norms + bin0 + 8 * g4 + 4 * hh);
+                    const float nn[4] = {n4.x, n4.y, n4.z, n4.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = fmaf(-2.0f, acc[4 * g4 + j], nn[j]);
+                        const int idx = bin0 + 8 * g4 + 4 * hh + j;
+                        if (v < best || (v == best && idx < besti)) { best = v; besti = idx; }
+                    }
+                }
+            }
+            {
+                const float ov = __shfl_xor(best, 32);
+                const int oi = __shfl_xor(besti, 32);
+                if (ov < best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+            }
+            if (lane < 32) { bd[wave * RVQM_FT + lane] = best; bi[wave * RVQM_FT + lane] = besti; }
+            __syncthreads();
+            if (tid < RVQM_FT) {
+                float v = bd[tid];
+                int ix = bi[tid];
+                for (int w2 = 1; w2 < 4; ++w2) {
+                    const float ov = bd[w2 * RVQM_FT + tid];
+                    const int oi = bi[w2 * RVQM_FT + tid];
+                    if (ov < v || (ov == v && oi < ix)) { v = ov; ix = oi; }
+                }
+                win[tid] = ix;
+                if (tid < nf) {
+                    const long long fr = f0 + tid, b = fr / T, t = fr - b * T;
+                    codes[(b * Q + q) * T + t] = ix;
+                }
+            }
+            __syncthreads();
+            for (int i = tid; i < RVQM_FT * D; i += 256) {
+                const int f = i / D, j = i - f * D;
+                R[f * RLD + j] = R[f * RLD + j] - tab[(size_t)win[f] * D + j];
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // Embedding(Q*bins, H)(codes + q*bins).mean(1): ordered sum then divide by Q.
 template <typename T>
 __global__ void __launch_bounds__(256) mean_embedding_kernel(const long long* __restrict__ codes, int B, int Q, int Tn, int bins,
@@ -937,6 +1083,19 @@ hipError_t q3_launch_rvq_encode(const float* emb, int B, int T, int in_dim, int 
     const long long frames = (long long)B * T;
     if (frames == 0) return hipSuccess;
     if ((D & 3) || D < 4 || in_dim < 1 || (!in_proj_dev && in_dim != D)) return hipErrorInvalidValue;
+    if (D == 256 && bins % 128 == 0 && !(q3_convgemm_tuning & 65536)) {       // full-size code books: the search on the fp32 matrix op
+        const size_t ldsm = ((size_t)RVQM_FT * (in_dim + 4 + D + 1) + 4 * RVQM_FT) * sizeof(float) + (4 * RVQM_FT + RVQM_FT) * sizeof(int);
+        if (ldsm <= 160 * 1024 && in_dim % 8 == 0) {
+            auto km = rvq_encode_mfma_kernel<256>;
+            hipError_t em = hipFuncSetAttribute((const void*)km, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm);
+            if (em != hipSuccess) return em;
+            const long long blocksm = (frames + RVQM_FT - 1) / RVQM_FT;
+            if (blocksm > 0x7fffffffLL) return hipErrorInvalidValue;
+            hipLaunchKernelGGL(km, dim3((unsigned)blocksm), dim3(256), ldsm, s, emb, frames, T, in_dim, Q, bins, tables_dev,
+                               (const float4* const*)tables_t_dev, group_start_dev, G, in_proj_dev, codes);
+            return hipGetLastError();
+        }
+    }
     const size_t lds = ((size_t)RVQ_FT * (in_dim + D) + 4 * RVQ_FT) * sizeof(float) + (4 * RVQ_FT + RVQ_FT) * sizeof(int);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     hipError_t e;

@@ -80,6 +80,32 @@ def test_encode_at_mimi_sizes_vs_oracle():
     assert snr_v >= 30.0 and abs(snr_v - snr) <= 3.0
 
 
+def test_rvq_search_kernels_agree():
+    """The code-book search runs on the fp32 matrix op when the code books are 256 wide (32 frames per block, four waves
+    splitting the 2048 codes); the vector-ALU kernel (the library's measurement switch) is the same exact argmin in another
+    summation order.  3 x 4.1 s of noise = 3 x 52 frames (four full blocks and a ragged fifth): the two must pick the same
+    code nearly everywhere (a near-tie may flip, and then the later code books of that frame follow)."""
+    from qwen3_tts_amd import _lib
+    ecfg = E.EncoderConfig()
+    cfg = q3.flagship_config()
+    w = {**q3.synthetic_weights(cfg, seed=0), **E.synthetic_encoder_weights(ecfg, cfg.codebook_dim, seed=3)}
+    audio = torch.randn(3, 98765, generator=torch.Generator().manual_seed(11)) * 0.3
+    dec = Decoder(cfg, w, device="cuda:0", precision="f32", encoder=ecfg)
+    lib = _lib.load()
+    a = dec.encode(audio).cpu()
+    try:
+        lib.q3c_debug_set_tuning(65536)
+        b = dec.encode(audio).cpu()
+    finally:
+        lib.q3c_debug_set_tuning(0)
+    assert a.shape == b.shape == (3, cfg.num_quantizers, ecfg.frames(98765))
+    first = float((a[:, 0] == b[:, 0]).float().mean())
+    frames_equal = float((a == b).all(dim=1).float().mean())
+    print(f"matrix-op vs vector-ALU search: first code book {100 * first:.2f} %, frames with all codes equal {100 * frames_equal:.2f} %")
+    assert int(a.min()) >= 0 and int(a.max()) < cfg.codebook_size
+    assert first >= 0.99 and frames_equal >= 0.97
+
+
 def test_encode_argument_errors(golden):
     meta, a = golden("encoder_tiny")
     ecfg, cfg, w = encoder_fixture(meta)
