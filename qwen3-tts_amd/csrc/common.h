@@ -18,12 +18,13 @@ enum Q3Act : int {
     Q3_ACT_SNAKE = 2,   // x + invb * sin(a x)^2 with per-output-channel (a, invb)
     Q3_ACT_SWIGLU = 3,  // adjacent 32-column tiles hold (gate, up); out = silu(gate) * up, N_out = N / 2
     Q3_ACT_CLAMP = 4,   // clamp(x, -1, 1)
+    Q3_ACT_ELU = 5,     // x > 0 ? x : exp(x) - 1
 };
 
 // h = scale[n] * act( bias[n] + sum_tap sum_k X[b, m + off0 + tap*off_step, k] * W[tap][n][k] )
 // with W2:  X <- pre(X) first (per-input-channel SnakeBeta: the fused residual unit reads the RAW stream), then
 //           h <- bias2[n] + sum_j h[., j] * W2[n][j]     (fused 1x1 second contraction; N == K2, scale unused)
-// y = R[b, m, n] + h;   Y <- post(y), or with Y2:  Y <- y and Y2 <- post(y)
+// y = R[b, m, n] + h;   Y <- post(y), or with Y2:  Y <- y and Y2 <- post(y)   (post: SnakeBeta with post_a / post_invb, or ELU with post_elu)
 // rows of X outside [0, L_in) read as zero.
 struct ConvGemmArgs {
     const void* X;  long long x_batch_stride; int ldx; int L_in;
@@ -37,6 +38,7 @@ struct ConvGemmArgs {
     const float* epi_a; const float* epi_invb;           // [N] for Q3_ACT_SNAKE
     const float* scale;                                  // [N_out] or null
     const float* post_a; const float* post_invb;         // [N_out] snake after the residual add, or null
+    int post_elu;                                        // 1: post is ELU (no parameters; not with W2)
     void* Y2; long long y2_batch_stride;                 // optional second output (row stride ldy)
     const int* row_start;                                // [B] or null: output rows below row_start[b] are stored as zeros
     int seg_len, seg_hist;                               // > 0: B == 1 and the M rows are segments of seg_len rows whose first
@@ -78,10 +80,10 @@ hipError_t q3_launch_mean_embedding(const long long* codes, int B, int Q, int T,
 // y[b, m] = act(bias + sum_t P[b, m - (taps - 1) + t, t]) over the rows m - (taps - 1) + t >= 0: the one-channel causal conv
 // whose per-tap products a fused unit left in P ([B][M][8] fp32); act: Q3_ACT_NONE or Q3_ACT_CLAMP
 hipError_t q3_launch_tap_sum(const float* P, const float* bias, float* y, int B, int M, int taps, int act, hipStream_t s);
-// ---- the encode side's small kernels: first conv (one audio channel -> F, k taps, causal), ELU over [B][n_item] with item
-// strides in elements, LayerNorm with bias, replicate padding ----
-hipError_t q3_launch_audio_conv(const float* audio, const float* w /*[F][k]*/, const float* bias, void* y, int B, int L, int F, int k, int dtype, hipStream_t s);
-hipError_t q3_launch_elu(const void* x, void* y, int B, long long n_item, long long x_bstride, long long y_bstride, int dtype, hipStream_t s);
+// ---- the encode side's small kernels: first conv (one audio channel -> F, k taps, causal; optionally also its ELU),
+// LayerNorm with bias, replicate padding ----
+// y2 (or null) receives ELU(y), items y2_bstride elements apart
+hipError_t q3_launch_audio_conv(const float* audio, const float* w /*[F][k]*/, const float* bias, void* y, void* y2, long long y2_bstride, int B, int L, int F, int k, int dtype, hipStream_t s);
 hipError_t q3_launch_layernorm(const void* x, const float* w, const float* bias, void* y, long long rows, int H, float eps, int dtype, hipStream_t s);
 hipError_t q3_launch_replicate_pad(const void* x, void* y, int B, int L, int C, int left, int Lout, int dtype, hipStream_t s);
 hipError_t q3_launch_rmsnorm(const void* x, const float* w, void* y, long long rows, int H, float eps, int dtype, hipStream_t s);
@@ -162,5 +164,12 @@ template <typename T> __device__ __forceinline__ float q3_snake(float x, float a
     return x + invb * (s * s);
 }
 __device__ __forceinline__ float q3_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// ELU (alpha = 1) without the library expm1f (dozens of instructions in an epilogue): exp(x) - 1 on the hardware exponential,
+// and the series x + x^2/2 + x^3/6 above -0.05 where that difference would cancel (truncation < 3e-7 absolute there)
+__device__ __forceinline__ float q3_elu(float x) {
+    const float ser = x * fmaf(x, fmaf(x, 0.16666667f, 0.5f), 1.0f);
+    const float ex = __expf(x) - 1.0f;
+    return x > 0.f ? x : (x > -0.05f ? ser : ex);
+}
 __device__ __forceinline__ float q3_silu(float x) { return x / (1.0f + expf(-x)); }
 #endif

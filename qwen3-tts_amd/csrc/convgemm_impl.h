@@ -739,7 +739,8 @@ convgemm_kernel(const ConvGemmArgs p) {
     // block applies one) is a wave-uniform choice per group of eight elements.
     const bool swiglu = !FUSE2 && p.act == Q3_ACT_SWIGLU;
     const int n_out = swiglu ? p.N / 2 : p.N;
-    const bool has_post = p.post_a != nullptr;
+    const bool post_elu = !FUSE2 && p.post_elu;           // the post activation is ELU, not SnakeBeta
+    const bool has_post = p.post_a != nullptr || post_elu;
     const bool has_res = FUSE2 || Rb != nullptr;
     const bool vec_ok = FUSE2 || ((p.ldy % EPO == 0) && (!Rb || p.ldr % EPO == 0) && (n_out % EPO == 0));
     const float* obias = FUSE2 ? p.bias2 : p.bias;
@@ -767,7 +768,7 @@ convgemm_kernel(const ConvGemmArgs p) {
             csc[j] = (p.scale && nv && !FUSE2) ? p.scale[n] : 1.f;
             cea[j] = ceib[j] = cqa[j] = cqib[j] = 0.f;
             if (first_act == Q3_ACT_SNAKE && nv) { cea[j] = p.epi_a[n]; ceib[j] = p.epi_invb[n]; }
-            if (has_post && nv) { cqa[j] = p.post_a[n]; cqib[j] = p.post_invb[n]; }
+            if (p.post_a && nv) { cqa[j] = p.post_a[n]; cqib[j] = p.post_invb[n]; }
         }
     };
     if constexpr (!FUSE2) column_params();
@@ -997,6 +998,7 @@ convgemm_kernel(const ConvGemmArgs p) {
                             if (first_act == Q3_ACT_GELU) v = q3_gelu(v);
                             else if (first_act == Q3_ACT_SNAKE) v = q3_snake<TO>(v, ea, eib);
                             else if (first_act == Q3_ACT_CLAMP) v = fminf(1.0f, fmaxf(-1.0f, v));
+                            else if (first_act == Q3_ACT_ELU) v = q3_elu(v);
                             if (!FUSE2) v *= sc;
                             if (has_res && !LATE) v += rr[r8];
                             vv[r8] = v;
@@ -1005,11 +1007,11 @@ convgemm_kernel(const ConvGemmArgs p) {
 #pragma unroll
                             for (int r8 = 0; r8 < 8; ++r8) {
                                 sa[((r8 & 3) + 8 * (r8 >> 2)) * SLD] = vv[r8];
-                                sb[((r8 & 3) + 8 * (r8 >> 2)) * SLD] = q3_snake<TO>(vv[r8], qa, qib);
+                                sb[((r8 & 3) + 8 * (r8 >> 2)) * SLD] = (post_elu ? q3_elu(vv[r8]) : q3_snake<TO>(vv[r8], qa, qib));
                             }
                         } else if (has_post) {
 #pragma unroll
-                            for (int r8 = 0; r8 < 8; ++r8) sa[((r8 & 3) + 8 * (r8 >> 2)) * SLD] = q3_snake<TO>(vv[r8], qa, qib);
+                            for (int r8 = 0; r8 < 8; ++r8) sa[((r8 & 3) + 8 * (r8 >> 2)) * SLD] = (post_elu ? q3_elu(vv[r8]) : q3_snake<TO>(vv[r8], qa, qib));
                         } else {
 #pragma unroll
                             for (int r8 = 0; r8 < 8; ++r8) sa[((r8 & 3) + 8 * (r8 >> 2)) * SLD] = vv[r8];
@@ -1160,6 +1162,7 @@ convgemm_kernel(const ConvGemmArgs p) {
                             if (first_act == Q3_ACT_GELU) v = q3_gelu(v);
                             else if (first_act == Q3_ACT_SNAKE) v = q3_snake<TO>(v, ea, eib);
                             else if (first_act == Q3_ACT_CLAMP) v = fminf(1.0f, fmaxf(-1.0f, v));
+                            else if (first_act == Q3_ACT_ELU) v = q3_elu(v);
                             if (!FUSE2) v *= sc;
                             if (has_res) v += rr[r8];
                             vv[r8] = v;
@@ -1168,11 +1171,11 @@ convgemm_kernel(const ConvGemmArgs p) {
 #pragma unroll
                             for (int r8 = 0; r8 < 8; ++r8) {
                                 sa[((r8 & 3) + 8 * (r8 >> 2)) * SLD] = vv[r8];
-                                sb[((r8 & 3) + 8 * (r8 >> 2)) * SLD] = q3_snake<TO>(vv[r8], qa, qib);
+                                sb[((r8 & 3) + 8 * (r8 >> 2)) * SLD] = (post_elu ? q3_elu(vv[r8]) : q3_snake<TO>(vv[r8], qa, qib));
                             }
                         } else if (has_post) {
 #pragma unroll
-                            for (int r8 = 0; r8 < 8; ++r8) sa[((r8 & 3) + 8 * (r8 >> 2)) * SLD] = q3_snake<TO>(vv[r8], qa, qib);
+                            for (int r8 = 0; r8 < 8; ++r8) sa[((r8 & 3) + 8 * (r8 >> 2)) * SLD] = (post_elu ? q3_elu(vv[r8]) : q3_snake<TO>(vv[r8], qa, qib));
                         } else {
 #pragma unroll
                             for (int r8 = 0; r8 < 8; ++r8) sa[((r8 & 3) + 8 * (r8 >> 2)) * SLD] = vv[r8];
@@ -1248,7 +1251,7 @@ hipError_t launch_cfg(const ConvGemmArgs& a_in, hipStream_t s) {
     if (xps > (BM * CPR + NTHR - 1) / NTHR || xps > 4) return hipErrorInvalidValue;      // halo too large for the staged-slice scheme
     if (a.W3 && !(FUSE2 && sizeof(TA) == 2 && WAVES_N == 1 && WN == JG && a.P && a.post_a && !a.Y2 && a.seg_len == 0 && a.N % 32 == 0 && a.N == BN))
         return hipErrorInvalidValue;
-    if (FUSE2 && (a.N > BN || a.K != a.N || !a.W2 || a.act != Q3_ACT_SNAKE || !a.epi_a || !a.epi_invb || !a.pre_a || !a.pre_invb || !a.R ||
+    if (FUSE2 && (a.post_elu || a.N > BN || a.K != a.N || !a.W2 || a.act != Q3_ACT_SNAKE || !a.epi_a || !a.epi_invb || !a.pre_a || !a.pre_invb || !a.R ||
                   a.ldy % 8 || a.ldr % 8 || a.N % 8))
         return hipErrorInvalidValue;
     const size_t xbuf = (size_t)((HR * CPR + 63) / 64) * 1024, wbuf = round_kb((size_t)BN * BKB), wring = 3 * wbuf + 1024;   // + a spare KiB for padding DMAs

@@ -278,6 +278,7 @@ struct GemmOpts {
     const float* scale = nullptr;
     const void* R = nullptr;
     const Snake* post = nullptr;
+    bool post_elu = false;            // the post activation is ELU (the encode side), not a SnakeBeta
     void* Y2 = nullptr;               // second output: Y gets the pre-`post` value, Y2 the post value
     const GemmW* second = nullptr;    // fused 1x1 second contraction (residual unit in one launch)
     const Snake* pre = nullptr;       // with `second`: SnakeBeta applied to the staged input tile (the unit reads the raw stream)
@@ -290,6 +291,7 @@ struct GemmOpts {
     int x_hist = 0;
     int off_shift = 0;                // added to the layer's first tap offset
     long long y_off = 0, y_bstride = 0, y2_off = 0, y2_bstride = 0, r_off = 0, r_bstride = 0;
+    long long x_bstride = 0;          // dense layout only: the input's items are this many elements apart (0: L_in rows)
     const int* row_start = nullptr;   // [B]: output rows below it are stored as zeros
 };
 
@@ -308,6 +310,7 @@ int gemm(q3c_ctx* c, const GemmW& g, const void* X, int B, int L_in, void* Y, in
     if (o.epi) { a.epi_a = o.epi->a; a.epi_invb = o.epi->invb; }
     a.scale = o.scale;
     if (o.post) { a.post_a = o.post->a; a.post_invb = o.post->invb; }
+    a.post_elu = o.post_elu ? 1 : 0;
     a.Y2 = o.Y2; a.y2_batch_stride = a.y_batch_stride;
     a.zeros = c->zero_page;
     a.row_start = o.row_start;
@@ -326,8 +329,14 @@ int gemm(q3c_ctx* c, const GemmW& g, const void* X, int B, int L_in, void* Y, in
         if (o.y_bstride) a.y_batch_stride = o.y_bstride;
         if (o.Y2) { a.Y2 = (char*)o.Y2 + o.y2_off * eo; a.y2_batch_stride = o.y2_bstride ? o.y2_bstride : a.y2_batch_stride; }
         if (o.R) { a.R = (const char*)o.R + o.r_off * eo; if (o.r_bstride) a.r_batch_stride = o.r_bstride; }
-    } else if (g.taps == 1 && M == L_in) {      // no halo: batch items are just more rows
-        a.M = B * M; a.L_in = B * L_in; a.B = 1;
+    } else {
+        // dense inputs whose outputs go to item-strided tensors (strides in elements of the output type)
+        if (o.x_bstride) a.x_batch_stride = o.x_bstride;
+        if (o.y_bstride) a.y_batch_stride = o.y_bstride;
+        if (o.Y2 && o.y2_bstride) a.y2_batch_stride = o.y2_bstride;
+        if (g.taps == 1 && M == L_in && !o.x_bstride && !o.y_bstride && !(o.Y2 && o.y2_bstride)) {      // no halo: batch items are just more rows
+            a.M = B * M; a.L_in = B * L_in; a.B = 1;
+        }
     }
     const char* pname = "";
     if (c->profiling) {

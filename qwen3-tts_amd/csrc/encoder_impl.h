@@ -3,9 +3,9 @@
 // Arithmetic: the sibling MimiModel.encode (transformers/models/mimi/modeling_mimi.py:1230-1263): conv encoder :450-492 with
 // residual blocks :408-447, transformer :729-779, stride-2 conv :1197-1206, split-RVQ encode :1099-1126.
 //
-// Data flow, channels-last [B][L][C] in the context's element type.  ELU sits in front of every conv but the first, so each
-// conv input is materialised by an elementwise ELU launch (the encoder is ~2 % of the decode's work per audio second; it is
-// not fused into the producers' epilogues).  A strided conv (kernel 2r, stride r, causal) over rows padded to a whole number
+// Data flow, channels-last [B][L][C] in the context's element type.  ELU sits in front of every conv but the first; the
+// producing launch writes it, as its activation or as a second output beside the raw tensor that a skip path needs, so no
+// elementwise launch remains.  A strided conv (kernel 2r, stride r, causal) over rows padded to a whole number
 // of strides is a two-tap contraction over the rows viewed as [L / r][r * C]:
 //   y[m] = W[:, :, 0:r] . x'[m - 1] + W[:, :, r:2r] . x'[m]
 // which is the decode side's transposed-conv trick run backwards.
@@ -119,36 +119,49 @@ int encode_sequence(q3c_ctx* c, int B, int L0, bool run, const float* audio, int
     auto alloc = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
     auto at = [&](size_t o) { return (void*)(ws + o); };
 
+    // x: a stage's raw input (its residual block's skip path); e: ELU(x), what the block's first conv reads, in the layout
+    // of the stage's strided conv (items padded to whole strides, the padding rows zero).  Each producer writes both.
     int L = L0, dim = k.num_filters;
     size_t o_x = alloc((size_t)B * L * dim * es);
-    if (run) LAUNCH_B(c, s, "audio_conv", (size_t)B * L * (4 + dim * es),
-                      q3_launch_audio_conv(audio, e.conv0_w, e.conv0_b, at(o_x), B, L, dim, k.kernel_size, dt, s));
-    for (const EncStage& st : e.stages) {
-        const int hid = dim / k.compress, r = st.r, Lp = (L + r - 1) / r * r;
-        const size_t o_e = alloc((size_t)B * Lp * dim * es), o_h = alloc((size_t)B * L * hid * es), o_y = alloc((size_t)B * (Lp / r) * 2 * dim * es);
+    auto padded = [&](int len, size_t i) { const int r = i < e.stages.size() ? e.stages[i].r : 1; return (len + r - 1) / r * r; };
+    int Lp = padded(L, 0);
+    size_t o_e = alloc((size_t)B * Lp * dim * es);
+    if (run) {
+        if (Lp != L) HIPCHK(c, hipMemsetAsync(at(o_e), 0, (size_t)B * Lp * dim * es, s));
+        LAUNCH_B(c, s, "audio_conv", (size_t)B * L * (4 + 2 * dim * es),
+                 q3_launch_audio_conv(audio, e.conv0_w, e.conv0_b, at(o_x), at(o_e), (long long)Lp * dim, B, L, dim, k.kernel_size, dt, s));
+    }
+    for (size_t si = 0; si < e.stages.size(); ++si) {
+        const EncStage& st = e.stages[si];
+        const int hid = dim / k.compress, r = st.r, Ln = Lp / r;
+        const size_t o_h = alloc((size_t)B * L * hid * es), o_y = alloc((size_t)B * Ln * 2 * dim * es);
+        const int Lpn = padded(Ln, si + 1);
+        const size_t o_en = alloc((size_t)B * Lpn * 2 * dim * es);
         if (run) {
-            const long long n = (long long)L * dim;
-            LAUNCH_B(c, s, "elu", 2.0 * B * n * es, q3_launch_elu(at(o_x), at(o_e), B, n, n, n, dt, s));
-            TRY(gemm(c, st.c3, at(o_e), B, L, at(o_h), L, dt, GemmOpts{}, s));
-            const long long nh = (long long)L * hid;
-            LAUNCH_B(c, s, "elu", 2.0 * B * nh * es, q3_launch_elu(at(o_h), at(o_h), B, nh, nh, nh, dt, s));
-            GemmOpts g1; g1.R = at(o_x);
-            TRY(gemm(c, st.c1, at(o_h), B, L, at(o_x), L, dt, g1, s));                      // x <- x + block(x), in place
-            if (Lp != L) HIPCHK(c, hipMemsetAsync(at(o_e), 0, (size_t)B * Lp * dim * es, s));  // the rows that pad an item to whole strides are zeros
-            LAUNCH_B(c, s, "elu", 2.0 * B * n * es, q3_launch_elu(at(o_x), at(o_e), B, n, n, (long long)Lp * dim, dt, s));
-            TRY(gemm(c, st.down, at(o_e), B, Lp / r, at(o_y), Lp / r, dt, GemmOpts{}, s));  // rows viewed as [Lp / r][r * dim]
+            // the block: h = ELU(conv3(e)); e <- ELU(x + conv1(h)) (x itself has no other reader); then the strided conv on e
+            // (rows viewed as [Lp / r][r * dim]) writes the next stage's x and e
+            GemmOpts g3; g3.act = Q3_ACT_ELU; g3.x_bstride = (long long)Lp * dim;
+            TRY(gemm(c, st.c3, at(o_e), B, L, at(o_h), L, dt, g3, s));   // reads the first L rows of each item of e
+            GemmOpts g1; g1.R = at(o_x); g1.post_elu = true; g1.y_bstride = (long long)Lp * dim;
+            TRY(gemm(c, st.c1, at(o_h), B, L, at(o_e), L, dt, g1, s));
+            if (Lpn != Ln) HIPCHK(c, hipMemsetAsync(at(o_en), 0, (size_t)B * Lpn * 2 * dim * es, s));
+            GemmOpts gd; gd.post_elu = true;
+            if (si + 1 < e.stages.size()) {
+                gd.Y2 = at(o_en); gd.y2_bstride = (long long)Lpn * 2 * dim;
+                TRY(gemm(c, st.down, at(o_e), B, Ln, at(o_y), Ln, dt, gd, s));
+            } else {
+                TRY(gemm(c, st.down, at(o_e), B, Ln, at(o_en), Ln, dt, gd, s));      // only the last conv reads this: ELU alone
+            }
         }
-        o_x = o_y; L = Lp / r; dim *= 2;
+        o_x = o_y; o_e = o_en; L = Ln; Lp = Lpn; dim *= 2;
     }
     const int H = k.hidden_size, I = k.intermediate_size, T = L;       // T: rows at the transformer's rate
     if (T > k.max_positions) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "audio longer than the encoder's max_positions");
-    const size_t o_e = alloc((size_t)B * T * dim * es), o_z = alloc((size_t)B * T * H * es), o_n = alloc((size_t)B * T * H * es);
+    const size_t o_z = alloc((size_t)B * T * H * es), o_n = alloc((size_t)B * T * H * es);
     const size_t o_qkv = alloc((size_t)B * T * 3 * H * es), o_att = alloc((size_t)B * T * H * es), o_mlp = alloc((size_t)B * T * I * es);
     const int sd = k.downsample_stride, Tg = (T + sd - 1) / sd;
     const size_t o_pad = alloc((size_t)B * (Tg + 1) * sd * H * es), o_emb = alloc((size_t)B * Tg * H * 4);
     if (run) {
-        const long long n = (long long)T * dim;
-        LAUNCH_B(c, s, "elu", 2.0 * B * n * es, q3_launch_elu(at(o_x), at(o_e), B, n, n, n, dt, s));
         TRY(gemm(c, e.last, at(o_e), B, T, at(o_z), T, dt, GemmOpts{}, s));
         void* x = at(o_z); void* nrm = at(o_n);
         const long long rows = (long long)B * T;

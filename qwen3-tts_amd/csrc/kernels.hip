@@ -601,10 +601,11 @@ __global__ void __launch_bounds__(256) swa_attention_kernel(const T* __restrict_
 
 // ---- the encode side's small kernels ---------------------------------------------------------------
 // First conv of the audio encoder: one input channel, k taps, causal zero padding.  A thread produces eight consecutive
-// channels of one sample (a 16-byte store in bf16); the F x k weights and the bias sit in LDS.
+// channels of one sample (a 16-byte store in bf16), and optionally their ELU into a second tensor (the input of the first
+// residual block's conv, whose skip path reads the raw one); the F x k weights and the bias sit in LDS.
 template <typename T>
 __global__ void __launch_bounds__(256) audio_conv_kernel(const float* __restrict__ audio, const float* __restrict__ w, const float* __restrict__ bias,
-                                                         T* __restrict__ y, int L, int F, int k) {
+                                                         T* __restrict__ y, T* __restrict__ y2 /*ELU(y), or null*/, long long y2_bstride, int L, int F, int k) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_enc[];
     float* ws = (float*)smem_enc;                    // [F][k] then [F]
     for (int i = threadIdx.x; i < F * k; i += 256) ws[i] = w[i];
@@ -626,27 +627,17 @@ __global__ void __launch_bounds__(256) audio_conv_kernel(const float* __restrict
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc[u] = fmaf(ws[(f0 + u) * k + j], av, acc[u]);
     }
-    T* dst = y + (b * L + t) * F + f0;
+    constexpr int V = (int)sizeof(T) * 8 / 16;       // 16-byte stores per eight channels
+    union { T e[8]; uint4 v[V]; } o, o2;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) dst[u] = q3_from_f32<T>(acc[u]);
-}
-
-// ELU (alpha = 1) of [B][n_item] elements, 16 bytes per thread and step; source and destination may have different item
-// strides (the destination of a strided conv's input is padded to a whole number of strides) and may be the same tensor.
-template <typename T>
-__global__ void __launch_bounds__(256) elu_kernel(const T* __restrict__ x, T* __restrict__ y, long long n_item, long long x_bstride, long long y_bstride) {
-    constexpr int EPV = 16 / (int)sizeof(T);
-    const long long b = blockIdx.y;
-    const long long nv = n_item / EPV;               // the launcher checks that items and strides are whole 16-byte pieces
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
-        uint4 v = *(const uint4*)(x + b * x_bstride + i * EPV);
-        T* e = (T*)&v;
+    for (int u = 0; u < 8; ++u) { o.e[u] = q3_from_f32<T>(acc[u]); o2.e[u] = q3_from_f32<T>(q3_elu(acc[u])); }
+    uint4* dst = (uint4*)(y + (b * L + t) * F + f0);
 #pragma unroll
-        for (int u = 0; u < EPV; ++u) {
-            const float f = q3_to_f32(e[u]);
-            e[u] = q3_from_f32<T>(f > 0.f ? f : expm1f(f));
-        }
-        *(uint4*)(y + b * y_bstride + i * EPV) = v;
+    for (int v = 0; v < V; ++v) dst[v] = o.v[v];
+    if (y2) {
+        uint4* dst2 = (uint4*)(y2 + b * y2_bstride + (long long)t * F + f0);
+#pragma unroll
+        for (int v = 0; v < V; ++v) dst2[v] = o2.v[v];
     }
 }
 
@@ -1083,7 +1074,7 @@ hipError_t q3_launch_rvq_encode(const float* emb, int B, int T, int in_dim, int 
     const long long frames = (long long)B * T;
     if (frames == 0) return hipSuccess;
     if ((D & 3) || D < 4 || in_dim < 1 || (!in_proj_dev && in_dim != D)) return hipErrorInvalidValue;
-    if (D == 256 && bins % 128 == 0 && !(q3_convgemm_tuning & 65536)) {       // full-size code books: the search on the fp32 matrix op
+    if (D == 256 && bins % 128 == 0 && !(q3_convgemm_tuning & (1 << 20))) {       // full-size code books: the search on the fp32 matrix op
         const size_t ldsm = ((size_t)RVQM_FT * (in_dim + 4 + D + 1) + 4 * RVQM_FT) * sizeof(float) + (4 * RVQM_FT + RVQM_FT) * sizeof(int);
         if (ldsm <= 160 * 1024 && in_dim % 8 == 0) {
             auto km = rvq_encode_mfma_kernel<256>;
@@ -1200,24 +1191,15 @@ hipError_t q3_launch_swa_attention(const void* qkv, void* out, const float* cos_
     return hipGetLastError();
 }
 
-hipError_t q3_launch_audio_conv(const float* audio, const float* w, const float* bias, void* y, int B, int L, int F, int k, int dtype, hipStream_t s) {
+hipError_t q3_launch_audio_conv(const float* audio, const float* w, const float* bias, void* y, void* y2, long long y2_bstride, int B, int L, int F,
+                                int k, int dtype, hipStream_t s) {
     if (B == 0 || L == 0) return hipSuccess;
     if (B > 65535 || F < 8 || (F & 7) || k < 1 || (size_t)F * (k + 1) * 4 > 48 * 1024) return hipErrorInvalidValue;
+    if (((uintptr_t)y & 15) || ((uintptr_t)y2 & 15) || (y2 && (y2_bstride & 7))) return hipErrorInvalidValue;
     const dim3 grid((unsigned)(((long long)L * (F / 8) + 255) / 256), B);
     const size_t lds = (size_t)F * (k + 1) * 4;
-    if (dtype == Q3_BF16) hipLaunchKernelGGL(audio_conv_kernel<bf16>, grid, dim3(256), lds, s, audio, w, bias, (bf16*)y, L, F, k);
-    else hipLaunchKernelGGL(audio_conv_kernel<float>, grid, dim3(256), lds, s, audio, w, bias, (float*)y, L, F, k);
-    return hipGetLastError();
-}
-
-hipError_t q3_launch_elu(const void* x, void* y, int B, long long n_item, long long x_bstride, long long y_bstride, int dtype, hipStream_t s) {
-    if (B == 0 || n_item == 0) return hipSuccess;
-    const int epv = dtype == Q3_BF16 ? 8 : 4;
-    if (B > 65535 || n_item % epv || x_bstride % epv || y_bstride % epv || ((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return hipErrorInvalidValue;
-    const long long blocks = (n_item / epv + 255) / 256;
-    const dim3 grid((unsigned)(blocks > 16384 ? 16384 : blocks), B);
-    if (dtype == Q3_BF16) hipLaunchKernelGGL(elu_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)x, (bf16*)y, n_item, x_bstride, y_bstride);
-    else hipLaunchKernelGGL(elu_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (float*)y, n_item, x_bstride, y_bstride);
+    if (dtype == Q3_BF16) hipLaunchKernelGGL(audio_conv_kernel<bf16>, grid, dim3(256), lds, s, audio, w, bias, (bf16*)y, (bf16*)y2, y2_bstride, L, F, k);
+    else hipLaunchKernelGGL(audio_conv_kernel<float>, grid, dim3(256), lds, s, audio, w, bias, (float*)y, (float*)y2, y2_bstride, L, F, k);
     return hipGetLastError();
 }
 

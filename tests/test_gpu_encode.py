@@ -94,7 +94,7 @@ def test_rvq_search_kernels_agree():
     lib = _lib.load()
     a = dec.encode(audio).cpu()
     try:
-        lib.q3c_debug_set_tuning(65536)
+        lib.q3c_debug_set_tuning(1 << 20)
         b = dec.encode(audio).cpu()
     finally:
         lib.q3c_debug_set_tuning(0)
