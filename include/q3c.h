@@ -96,6 +96,16 @@ int q3c_output_length(const q3c_ctx* ctx, int32_t frames, int64_t* samples);
 int q3c_forward(q3c_ctx* ctx, const int64_t* codes_dev, int32_t batch, int32_t frames, float* wav_dev,
                 void* workspace_dev, size_t workspace_bytes, void* hip_stream);
 
+/* q3c_forward for one chunk of chunked_decode (sib :3686-3696): the chunk's first skip_frames frames are its recomputed left
+ * context, whose samples the caller drops (`wav_chunk[..., context * total_upsample:]`, :3694).  Same arguments and the same
+ * wav layout as q3c_forward; the samples from skip_frames * total_upsample on are bit for bit those q3c_forward writes, the
+ * samples before are NOT written.  The conv decoder is causal with a finite look-back per layer, so each of its launches
+ * starts at the first row a kept sample can see and the rest of the context's rows (24 of 25 frames at the sample rate) is
+ * never computed; the frame-rate stages run whole.  0 <= skip_frames < frames.  While a stage tap is set the whole forward
+ * runs. */
+int q3c_forward_skip(q3c_ctx* ctx, const int64_t* codes_dev, int32_t batch, int32_t frames, int32_t skip_frames, float* wav_dev,
+                     void* workspace_dev, size_t workspace_bytes, void* hip_stream);
+
 /* q3c_forward for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses
  * that forbid hipMalloc).  It has no counterpart in the reference.  Same result as q3c_forward, bit for bit, but the workspace is
  * a static device array of Q3C_STATIC_SCRATCH_BYTES inside the library (each GPU the library runs on holds its own copy

@@ -25,7 +25,7 @@ enum Q3Act : int {
 // with W2:  X <- pre(X) first (per-input-channel SnakeBeta: the fused residual unit reads the RAW stream), then
 //           h <- bias2[n] + sum_j h[., j] * W2[n][j]     (fused 1x1 second contraction; N == K2, scale unused)
 // y = R[b, m, n] + h;   Y <- post(y), or with Y2:  Y <- y and Y2 <- post(y)   (post: SnakeBeta with post_a / post_invb, or ELU with post_elu)
-// rows of X outside [0, L_in) read as zero.
+// rows of X outside [row_lo, L_in) read as zero.
 struct ConvGemmArgs {
     const void* X;  long long x_batch_stride; int ldx; int L_in;
     const void* W;                       // [taps][N][K]
@@ -54,6 +54,9 @@ struct ConvGemmArgs {
     int tile_order;                                      // 0: N tile slowest, 1: N tile fastest, G >= 2: N tiles in groups of G (set by the launcher)
     int debug;                                           // measurement aid: bit 4 = plain (not XCD-grouped) tile order
     const void* zeros;                                   // >= 16 bytes of zeros in device memory (source of out-of-sequence rows)
+    int row_lo;                                          // 0, or negative: X points |row_lo| rows INTO a sequence whose earlier rows exist
+                                                         // and are read as the halo (a launch that computes the sequence's tail only)
+    int shape_rows;                                      // > 0: choose the tile shape as for this many rows per item instead of M
     long long* timeline; int timeline_slots;             // measurement aid (null normally): every 64th workgroup stores the
                                                          // clock at its phase boundaries, 8 values per slot
 };
@@ -79,7 +82,8 @@ hipError_t q3_launch_mean_embedding(const long long* codes, int B, int Q, int T,
                                     const float* table, void* out, int out_dtype, int* err_flag, hipStream_t s);
 // y[b, m] = act(bias + sum_t P[b, m - (taps - 1) + t, t]) over the rows m - (taps - 1) + t >= 0: the one-channel causal conv
 // whose per-tap products a fused unit left in P ([B][M][8] fp32); act: Q3_ACT_NONE or Q3_ACT_CLAMP
-hipError_t q3_launch_tap_sum(const float* P, const float* bias, float* y, int B, int M, int taps, int act, hipStream_t s);
+// m_first: rows below it are not written (their P rows may not exist; the rows m_first - (taps - 1) .. do)
+hipError_t q3_launch_tap_sum(const float* P, const float* bias, float* y, int B, int M, int taps, int act, hipStream_t s, int m_first = 0);
 // ---- the encode side's small kernels: first conv (one audio channel -> F, k taps, causal; optionally also its ELU),
 // LayerNorm with bias, replicate padding ----
 // y2 (or null) receives ELU(y), items y2_bstride elements apart

@@ -232,7 +232,7 @@ convgemm_kernel(const ConvGemmArgs p) {
         int grow = g0 + row;
         int kel = kc * BK + my_c * EPC;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (id < xpieces && grow >= 0 && grow < p.L_in && kel < p.K) {
+        if (id < xpieces && grow >= p.row_lo && grow < p.L_in && kel < p.K) {
             v = *(const uint4*)(Xb + (long long)grow * p.ldx + kel);
             if constexpr (FUSE2) {                   // the unit's first SnakeBeta, here in registers
                 TA* e = (TA*)&v;
@@ -275,7 +275,7 @@ convgemm_kernel(const ConvGemmArgs p) {
     constexpr int XROWS_PER_IT = NTHR / CPR;                     // rows one iteration of all waves covers (a multiple of 16)
     const int xrow0 = tid / CPR;
     // a tile whose staged rows (padding lanes included) all lie inside the sequence needs no per-lane checks
-    const bool interior = g0 >= 0 && (g0 + xi_total * XROWS_PER_IT) <= p.L_in;
+    const bool interior = g0 >= p.row_lo && (g0 + xi_total * XROWS_PER_IT) <= p.L_in;
     const TA* xtile = Xb + (long long)g0 * p.ldx;                                      // wave-uniform
     const unsigned xvoff0 = (unsigned)((xrow0 * p.ldx + swz<CPR>(xrow0, my_c) * EPC) * (int)sizeof(TA));
     // input rows [it*XROWS_PER_IT ...) of chunk kc -> buffer at xs; rows outside the sequence come from the zero page
@@ -288,7 +288,7 @@ convgemm_kernel(const ConvGemmArgs p) {
         } else {
             const int grow = g0 + xrow0 + it * XROWS_PER_IT;
             const unsigned long long real = (unsigned long long)sbase + xvoff0;
-            const unsigned long long src = (grow >= 0 && grow < p.L_in) ? real : (unsigned long long)zero_page;
+            const unsigned long long src = (grow >= p.row_lo && grow < p.L_in) ? real : (unsigned long long)zero_page;
             dma16((const void*)src, xs + (unsigned)slot * 1024u);
         }
     };
@@ -1303,6 +1303,9 @@ enum { SH_256x96 = 0, SH_256x128_K128, SH_128x128_K128, SH_128x128_K64, SH_256x3
        SH_256x128_K64, SH_F_128x192, SH_F_128x384, SH_COUNT };
 
 int pick_shape(const ConvGemmArgs& a, size_t elem) {
+    // rows that decide the shape: a launch that computes only the tail of its rows keeps the whole tensor's shape (the shape
+    // fixes the order in which K chunks and taps are summed, and the tail must come out bit for bit as in the whole launch)
+    const long long rows_all = (long long)a.B * (a.shape_rows > 0 ? a.shape_rows : a.M);
     if (a.W2) {                                   // fused residual unit: one N tile must hold every channel
         if (a.N <= 32) return SH_F_256x32;
         if (a.N <= 96) return SH_F_256x96;       // (128-row tiles, three blocks per CU: measured 9 % slower)
@@ -1317,15 +1320,15 @@ int pick_shape(const ConvGemmArgs& a, size_t elem) {
     const bool wide_k = ((size_t)a.K * elem) % 128 == 0;
     if (a.N <= 32 && a.act != Q3_ACT_SWIGLU) return SH_256x32;
     const bool use_96 = (a.act != Q3_ACT_SWIGLU) && (a.N % 128 != 0) && (a.N % 96 == 0) && a.N < 512;
-    if (use_96 && (a.N <= 96 || (long long)a.B * a.M < 8192 || (q3_convgemm_tuning & 8))) return SH_256x96;     // larger N: more waves per CU beat exact tiling (memory-bound layers)
+    if (use_96 && (a.N <= 96 || rows_all < 8192 || (q3_convgemm_tuning & 8))) return SH_256x96;     // larger N: more waves per CU beat exact tiling (memory-bound layers)
     if (!wide_k) return SH_128x128_K64;
     // Layers with enough rows to fill the chip: 256x128 tiles with 64-byte K rows need 65-73 KB of LDS, so TWO blocks
     // (16 waves) share a CU and one block's prologue, barriers and epilogue hide under the other's MFMAs (measured against one 129-KB block with
     // 128-byte rows: k = 7 convs +6..14 %, k = 1 convs +36..49 %, transposed convs +6..19 %).
-    if (!(q3_convgemm_tuning & 2) && (long long)a.B * a.M >= 8192) return SH_256x128_K64;
+    if (!(q3_convgemm_tuning & 2) && rows_all >= 8192) return SH_256x128_K64;
     // Few rows (a streaming push, a short utterance): 128-row tiles on four waves double the number of blocks when
     // 256-row tiles would leave most of the 256 CUs idle (256 streams x 1 frame: push 5.75 -> 5.46 ms)
-    const long long tiles256 = (((long long)a.B * a.M + 255) / 256) * ((a.N + 127) / 128);
+    const long long tiles256 = ((rows_all + 255) / 256) * ((a.N + 127) / 128);
     const bool small = tiles256 < 512;
     return (small != ((q3_convgemm_tuning & 1) != 0)) ? SH_128x128_K128 : SH_256x128_K128;
 }

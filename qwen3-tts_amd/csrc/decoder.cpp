@@ -293,6 +293,8 @@ struct GemmOpts {
     long long y_off = 0, y_bstride = 0, y2_off = 0, y2_bstride = 0, r_off = 0, r_bstride = 0;
     long long x_bstride = 0;          // dense layout only: the input's items are this many elements apart (0: L_in rows)
     const int* row_start = nullptr;   // [B]: output rows below it are stored as zeros
+    int row0 = 0;                     // dense layout only: output rows below row0 are NOT computed (nobody reads them); their
+                                      // inputs exist, so the rows in front of row0 serve as the halo
 };
 
 // X [B][L_in][K] contiguous -> Y [B][M][N_out] contiguous (N_out = N, or N/2 for SwiGLU); R like Y.
@@ -334,24 +336,36 @@ int gemm(q3c_ctx* c, const GemmW& g, const void* X, int B, int L_in, void* Y, in
         if (o.x_bstride) a.x_batch_stride = o.x_bstride;
         if (o.y_bstride) a.y_batch_stride = o.y_bstride;
         if (o.Y2 && o.y2_bstride) a.y2_batch_stride = o.y2_bstride;
-        if (g.taps == 1 && M == L_in && !o.x_bstride && !o.y_bstride && !(o.Y2 && o.y2_bstride)) {      // no halo: batch items are just more rows
+        if (g.taps == 1 && M == L_in && !o.x_bstride && !o.y_bstride && !(o.Y2 && o.y2_bstride) && !o.row0) {      // no halo: batch items are just more rows
             a.M = B * M; a.L_in = B * L_in; a.B = 1;
         }
+        if (o.row0 > 0) {             // every tensor starts row0 rows further on; the item strides stay those of the whole tensors
+            if (o.row0 >= M) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "first computed row beyond the output");
+            const size_t ei = esize(g.in_dtype), eo = esize(out_dtype);
+            a.X = (const char*)a.X + (size_t)o.row0 * a.ldx * ei;
+            a.Y = (char*)a.Y + (size_t)o.row0 * a.ldy * eo;
+            if (a.Y2) a.Y2 = (char*)a.Y2 + (size_t)o.row0 * a.ldy * eo;
+            if (a.R) a.R = (const char*)a.R + (size_t)o.row0 * a.ldr * eo;
+            if (a.P) a.P += (size_t)o.row0 * 8;
+            a.shape_rows = a.M;       // same tile shape, hence the same summation order, as the whole launch
+            a.M -= o.row0; a.L_in -= o.row0; a.row_lo = -o.row0;
+        }
     }
+    const int Mc = o.segmented ? M : M - o.row0;      // rows computed per item
     const char* pname = "";
     if (c->profiling) {
         pname = q3_convgemm_variant(a, g.in_dtype, out_dtype);
         if (c->profile_detail) {      // one entry per layer shape: interned so the pointer outlives this call
             char buf[64];
-            std::snprintf(buf, sizeof(buf), "%.24s M%dxN%dxK%dxT%d%s", pname + 9, B * M, a.N, a.K, a.taps, o.second ? "+1x1" : "");
+            std::snprintf(buf, sizeof(buf), "%.24s M%dxN%dxK%dxT%d%s", pname + 9, B * Mc, a.N, a.K, a.taps, o.second ? "+1x1" : "");
             pname = c->interned.insert(buf).first->c_str();
         }
     }
     // algorithmic bytes: input, weights, and each output / residual tensor once
     // (the fused unit's residual rows are rows of its input tensor, read moments before: not a second stream)
-    const double abytes = (double)B * L_in * g.K * esize(g.in_dtype) + (double)g.taps * g.N * g.K * esize(g.in_dtype) +
-                          (double)B * M * n_out * esize(out_dtype) * (1 + (o.Y2 ? 1 : 0) + ((o.R && !o.second) ? 1 : 0));
-    ProfScope ps(c, s, pname, 2.0 * B * M * (double)a.N * (a.K * a.taps + (o.second ? a.N : 0)), abytes);
+    const double abytes = (double)B * (L_in - (o.segmented ? 0 : o.row0)) * g.K * esize(g.in_dtype) + (double)g.taps * g.N * g.K * esize(g.in_dtype) +
+                          (double)B * Mc * n_out * esize(out_dtype) * (1 + (o.Y2 ? 1 : 0) + ((o.R && !o.second) ? 1 : 0));
+    ProfScope ps(c, s, pname, 2.0 * B * Mc * (double)a.N * (a.K * a.taps + (o.second ? a.N : 0)), abytes);
     hipError_t e = q3_launch_convgemm(a, g.in_dtype, out_dtype, s);
     if (e != hipSuccess) return fail(c, Q3C_ERR_HIP, std::string("convgemm launch: ") + hipGetErrorString(e));
     return 0;
@@ -1062,7 +1076,8 @@ int q3c_rvq_dequant_f32(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, 
     return 0;
 }
 
-static int forward_impl(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, float* wav, void* ws, size_t ws_bytes, void* stream);
+static int forward_impl(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, float* wav, void* ws, size_t ws_bytes, void* stream,
+                        int32_t skip_frames = 0);
 
 int q3c_rvq_encode(q3c_ctx* c, const float* emb, int32_t B, int32_t T, int32_t in_dim, int64_t* codes, void* stream) {
     if (!c) return Q3C_ERR_INVALID_ARGUMENT;
@@ -1086,6 +1101,15 @@ int q3c_forward(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, float* w
     return forward_impl(c, codes, B, T, wav, ws, ws_bytes, stream);
 }
 
+int q3c_forward_skip(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, int32_t skip_frames, float* wav, void* ws, size_t ws_bytes,
+                     void* stream) {
+    if (!c) return Q3C_ERR_INVALID_ARGUMENT;
+    if (!c->finalized) return fail(c, Q3C_ERR_STATE, "q3c_finalize has not run");
+    if (!codes || !wav || !ws || B < 1 || T < 1) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "q3c_forward_skip: bad argument");
+    if (skip_frames < 0 || skip_frames >= T) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "q3c_forward_skip: skip_frames must be in [0, frames)");
+    return forward_impl(c, codes, B, T, wav, ws, ws_bytes, stream, skip_frames);
+}
+
 // q3c_forward on the library's static workspace: no device memory is allocated or freed here or in anything it calls
 // (launches, events and taps included: profiling, the one consumer of hipEventCreate, is refused).
 int q3c_forward_static(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, float* wav, void* stream) {
@@ -1103,7 +1127,8 @@ int q3c_forward_static(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, f
     return forward_impl(c, codes, B, T, wav, c->static_scratch, (size_t)Q3C_STATIC_SCRATCH_BYTES, stream);
 }
 
-static int forward_impl(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, float* wav, void* ws, size_t ws_bytes, void* stream) {
+static int forward_impl(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, float* wav, void* ws, size_t ws_bytes, void* stream,
+                        int32_t skip_frames) {
     const q3c_config& k = c->cfg;
     if (T > k.max_positions) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "frames exceed max_positions");
     if ((uintptr_t)ws & 255) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "workspace must be 256-byte aligned");
@@ -1160,9 +1185,40 @@ static int forward_impl(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, 
         TRY(tap_out(c, Q3C_STAGE_UPSAMPLE0 + i, cur, rows * Lt, s));
     }
 
+    // ---- rows nobody reads ----
+    // With skip_frames > 0 the caller discards the samples of the first skip_frames frames (a chunk's recomputed left context,
+    // sibling :3691-3695).  Every layer of the conv decoder is causal with a finite look-back, so the rows under those samples
+    // are needed only as far as a kept sample's look-back reaches: walking back from the first kept sample gives, per launch,
+    // the first row that has to be computed.  A row's arithmetic does not depend on which rows are computed beside it, so the
+    // kept samples are bit for bit those of the whole forward.  The frame-rate stages (attention window: 72 frames) run whole.
+    const size_t nblk = c->blocks.size();
+    std::vector<int> tconv_row0(nblk, 0);
+    std::vector<std::vector<int>> unit_row0(nblk);
+    for (size_t i = 0; i < nblk; ++i) unit_row0[i].assign(c->blocks[i].units.size(), 0);
+    int out_row0 = 0, conv_in_row0 = 0;
+    for (const auto& t : c->taps) if (t.second.first) skip_frames = 0;       // a captured stage is captured whole
+    if (skip_frames > 0) {
+        long long per_frame = 1;
+        for (int i = 0; i < k.num_upsampling_ratios; ++i) per_frame *= k.upsampling_ratios[i];
+        for (int i = 0; i < k.num_upsample_rates; ++i) per_frame *= k.upsample_rates[i];
+        long long need = (long long)skip_frames * per_frame;                 // the first kept sample
+        out_row0 = (int)need;
+        need = std::max(0LL, need - (long long)(c->conv_out.taps - 1) * c->conv_out.off_step);
+        for (size_t i = nblk; i-- > 0;) {
+            const Block& b = c->blocks[i];
+            for (size_t j = b.units.size(); j-- > 0;) {
+                unit_row0[i][j] = (int)need;
+                need = std::max(0LL, need - (long long)(b.units[j].c1.taps - 1) * b.units[j].c1.off_step);
+            }
+            need /= b.rate;                   // output rows q * rate .. of the transposed conv come from its input rows q, q + 1
+            tconv_row0[i] = (int)need;
+        }
+        conv_in_row0 = (int)need;
+    }
+
     // ---- conv decoder ----
     {
-        GemmOpts g; g.post = &c->blocks[0].head;
+        GemmOpts g; g.post = &c->blocks[0].head; g.row0 = conv_in_row0;
         TRY(gemm(c, c->conv_in, cur, B, L, other, L, dt, g, s));
         std::swap(cur, other);
         TRY(tap_out(c, Q3C_STAGE_CONV_IN, cur, (size_t)B * L * k.decoder_dim, s));
@@ -1187,7 +1243,7 @@ static int forward_impl(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, 
         const bool fuse = c->fuse_units && q3_convgemm_fusable(ch, dt);
         {
             // fused units read the raw stream and apply their own first SnakeBeta: the transposed conv then writes ONE tensor
-            GemmOpts g;
+            GemmOpts g; g.row0 = tconv_row0[i];
             if (!fuse) { g.post = &b.first_act_tiled; g.Y2 = sn; }
             TRY(gemm(c, b.tconv, cur, B, L, raw, Lq, dt, g, s));              // [B, L-1, r*ch] == [B, (L-1)*r, ch]
         }
@@ -1200,7 +1256,7 @@ static int forward_impl(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, 
                 // snake -> conv k7 -> snake -> conv k1 -> + x in one launch on the RAW stream: one tensor in (read with a
                 // halo, so the result goes to the other buffer), one tensor out; only the block's last unit applies a
                 // consumer's SnakeBeta (the next block's head, or the final one), to its single output
-                GemmOpts g; g.act = Q3_ACT_SNAKE; g.epi = &u.a2; g.second = &u.c2; g.pre = &u.a1; g.R = raw;
+                GemmOpts g; g.act = Q3_ACT_SNAKE; g.epi = &u.a2; g.second = &u.c2; g.pre = &u.a1; g.R = raw; g.row0 = unit_row0[i][j];
                 if (last) g.post = post;
                 // The decoder's last unit: its output (final SnakeBeta applied) is read by the one-channel final conv alone, so
                 // it is never stored: the unit's epilogue leaves the conv's per-tap products, 8 floats per row, in `sn`.
@@ -1208,9 +1264,9 @@ static int forward_impl(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, 
                 TRY(gemm(c, u.c1, raw, B, L, sn, L, dt, g, s));
                 if (!last) std::swap(raw, sn);     // the last unit's (snaked) output stays in `sn`: the block's output
             } else {
-                GemmOpts g1; g1.act = Q3_ACT_SNAKE; g1.epi = &u.a2;
+                GemmOpts g1; g1.act = Q3_ACT_SNAKE; g1.epi = &u.a2; g1.row0 = unit_row0[i][j];
                 TRY(gemm(c, u.c1, sn, B, L, sp, L, dt, g1, s));
-                GemmOpts g2; g2.R = raw; g2.post = post;
+                GemmOpts g2; g2.R = raw; g2.post = post; g2.row0 = unit_row0[i][j];
                 if (last) { TRY(gemm(c, u.c2, sp, B, L, sn, L, dt, g2, s)); }
                 else { g2.Y2 = sn; TRY(gemm(c, u.c2, sp, B, L, raw, L, dt, g2, s)); }
             }
@@ -1221,10 +1277,10 @@ static int forward_impl(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, 
         if (!(folded && i + 1 == c->blocks.size())) TRY(tap_out(c, Q3C_STAGE_BLOCK0 + (int)i, cur, (size_t)B * L * ch, s));
     }
     if (folded) {   // the final conv's taps summed along the diagonal of the products, bias, clamp
-        LAUNCH_B(c, s, "tap_sum", (size_t)B * L * 36,
-                 q3_launch_tap_sum((const float*)cur, c->conv_out.bias, wav, B, L, c->conv_out.taps, Q3_ACT_CLAMP, s));
+        LAUNCH_B(c, s, "tap_sum", (size_t)B * (L - out_row0) * 36,
+                 q3_launch_tap_sum((const float*)cur, c->conv_out.bias, wav, B, L, c->conv_out.taps, Q3_ACT_CLAMP, s, out_row0));
     } else {        // final conv to one channel, clamp fused, fp32 samples out
-        GemmOpts g; g.act = Q3_ACT_CLAMP;
+        GemmOpts g; g.act = Q3_ACT_CLAMP; g.row0 = out_row0;
         TRY(gemm(c, c->conv_out, cur, B, L, wav, L, Q3_F32, g, s));
     }
     return 0;

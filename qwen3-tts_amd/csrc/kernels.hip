@@ -674,10 +674,10 @@ __global__ void __launch_bounds__(256) replicate_pad_kernel(const T* __restrict_
 // y[b][m] = act(bias + sum_t P[b][m - (taps - 1) + t][t]).  A block stages its 256 rows and the 8 before them in LDS (rows of
 // 9 floats: the diagonal reads of consecutive lanes then fall on distinct banks).
 __global__ void __launch_bounds__(256) tap_sum_kernel(const float* __restrict__ P, const float* __restrict__ bias, float* __restrict__ y,
-                                                      int M, int taps, int act) {
+                                                      int M, int taps, int act, int m_first) {
     __shared__ float sm[(256 + 8) * 9];
     const long long b = blockIdx.y;
-    const int m0 = blockIdx.x * 256, tid = threadIdx.x;
+    const int m0 = m_first + blockIdx.x * 256, tid = threadIdx.x;
     const float4* Pb = (const float4*)(P + b * (long long)M * 8);
     for (int i = tid; i < (256 + 8) * 2; i += 256) {
         const int lr = i >> 1, row = m0 - 8 + lr;
@@ -1221,10 +1221,10 @@ hipError_t q3_launch_replicate_pad(const void* x, void* y, int B, int L, int C, 
     return hipGetLastError();
 }
 
-hipError_t q3_launch_tap_sum(const float* P, const float* bias, float* y, int B, int M, int taps, int act, hipStream_t s) {
+hipError_t q3_launch_tap_sum(const float* P, const float* bias, float* y, int B, int M, int taps, int act, hipStream_t s, int m_first) {
     if (B == 0 || M == 0) return hipSuccess;
-    if (taps < 1 || taps > 8 || B > 65535) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(tap_sum_kernel, dim3((M + 255) / 256, B), dim3(256), 0, s, P, bias, y, M, taps, act);
+    if (taps < 1 || taps > 8 || B > 65535 || m_first < 0 || m_first >= M) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(tap_sum_kernel, dim3((M - m_first + 255) / 256, B), dim3(256), 0, s, P, bias, y, M, taps, act, m_first);
     return hipGetLastError();
 }
 

@@ -104,6 +104,7 @@ class Decoder:
         self.precision = precision
         self.max_positions = int(max_positions)
         self.max_frames_per_launch = int(max_frames_per_launch)
+        self.skip_context = True        # chunked decodes do not compute the conv-decoder rows under a chunk's dropped context
         self._lib = _lib.load()
         self._ctx = C.c_void_p()
         self._ws: Optional[torch.Tensor] = None
@@ -177,19 +178,29 @@ class Decoder:
         return codes.to(device=self.device, dtype=torch.int64).contiguous()
 
     # ------------------------------------------------------------------------------------------------
-    def forward(self, codes: torch.Tensor, check_codes: bool = False) -> torch.Tensor:
-        """codes [B, Q, T] int64 -> wav [B, 1, T*1920 - 555] float32 on the device, clamped to [-1, 1]."""
+    def forward(self, codes: torch.Tensor, check_codes: bool = False, skip_frames: int = 0) -> torch.Tensor:
+        """codes [B, Q, T] int64 -> wav [B, 1, T*1920 - 555] float32 on the device, clamped to [-1, 1].
+        skip_frames > 0 (a chunk's left context, q3c_forward_skip): the samples of the first skip_frames frames are left
+        unwritten and the rows of the conv decoder that only they depend on are not computed; the other samples are bit
+        for bit those of skip_frames = 0."""
         codes = self._codes_tensor(codes)
         B, _, T = codes.shape
         if T < 1 or B < 1:
             raise ValueError("empty codes")
+        if not 0 <= skip_frames < T:
+            raise ValueError(f"skip_frames must be in [0, {T}), got {skip_frames}")
         n = self.cfg.output_length(T)
         wav = torch.empty((B, 1, n), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             ws = self._workspace(B, T)
             base = (ws.data_ptr() + 255) // 256 * 256
-            self._check(self._lib.q3c_forward(self._ctx, C.c_void_p(codes.data_ptr()), B, T, C.c_void_p(wav.data_ptr()),
-                                              C.c_void_p(base), ws.numel() - (base - ws.data_ptr()), self._stream()))
+            if skip_frames:
+                self._check(self._lib.q3c_forward_skip(self._ctx, C.c_void_p(codes.data_ptr()), B, T, skip_frames,
+                                                       C.c_void_p(wav.data_ptr()), C.c_void_p(base),
+                                                       ws.numel() - (base - ws.data_ptr()), self._stream()))
+            else:
+                self._check(self._lib.q3c_forward(self._ctx, C.c_void_p(codes.data_ptr()), B, T, C.c_void_p(wav.data_ptr()),
+                                                  C.c_void_p(base), ws.numel() - (base - ws.data_ptr()), self._stream()))
             if check_codes:
                 self._check(self._lib.q3c_check_errors(self._ctx, self._stream()))
         return wav
@@ -228,16 +239,18 @@ class Decoder:
         for s, e, ctx in plan:
             offsets.append(off)
             off += self.cfg.output_length(e - s) - ctx * up
-        groups: Dict[int, List[int]] = {}
-        for j, (s, e, _ctx) in enumerate(plan):
-            groups.setdefault(e - s, []).append(j)
-        for length, idxs in groups.items():
+        # chunks of equal length AND equal context share a launch sequence: the context's samples are dropped below, so the
+        # launch skips the rows only they depend on (forward's skip_frames)
+        groups: Dict[Tuple[int, int], List[int]] = {}
+        for j, (s, e, ctx) in enumerate(plan):
+            groups.setdefault((e - s, ctx if self.skip_context else 0), []).append(j)
+        for (length, skip), idxs in groups.items():
             per = max(1, self.max_frames_per_launch // (length * B))
             for i0 in range(0, len(idxs), per):
                 sub = idxs[i0:i0 + per]
                 stacked = torch.cat([codes[..., plan[j][0]:plan[j][1]] for j in sub], dim=0) if len(sub) > 1 \
                     else codes[..., plan[sub[0]][0]:plan[sub[0]][1]]
-                wav = self.forward(stacked)
+                wav = self.forward(stacked, skip_frames=skip)
                 for n, j in enumerate(sub):
                     ctx = plan[j][2]
                     piece = wav[n * B:(n + 1) * B, :, ctx * up:]
@@ -377,10 +390,10 @@ class Decoder:
                 o += int(c.shape[1])
         else:
             dev_items = [c.to(self.device) for c in items]
-        buckets: Dict[int, List[int]] = {}
-        for j, (_i, s, e, _ctx, _off) in enumerate(jobs):
-            buckets.setdefault(-(-(e - s) // pad_to) * pad_to, []).append(j)
-        for Lb, idxs in sorted(buckets.items()):
+        buckets: Dict[Tuple[int, int], List[int]] = {}
+        for j, (_i, s, e, ctx, _off) in enumerate(jobs):
+            buckets.setdefault((-(-(e - s) // pad_to) * pad_to, ctx if self.skip_context else 0), []).append(j)
+        for (Lb, skip), idxs in sorted(buckets.items()):
             per = max(1, self.max_frames_per_launch // Lb)
             for i0 in range(0, len(idxs), per):
                 sub = idxs[i0:i0 + per]
@@ -388,7 +401,7 @@ class Decoder:
                 for n, j in enumerate(sub):
                     i, s, e, _ctx, _off = jobs[j]
                     batch[n, :, : e - s] = dev_items[i][:, s:e]
-                wav = self.forward(batch)
+                wav = self.forward(batch, skip_frames=skip)
                 for n, j in enumerate(sub):
                     i, s, e, ctx, off = jobs[j]
                     keep = self.cfg.output_length(e - s) - ctx * up

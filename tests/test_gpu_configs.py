@@ -459,3 +459,68 @@ def test_narrow_transformer_architecture_vs_oracle():
     for stage in ("rvq_out", "transformer_in", "transformer_out", "upsample1", "conv_in+snake"):
         assert by[stage][2] >= BF16_STAGE_SNR_DB[stage], f"{stage}\n" + format_report(rows16)
     assert by["wav"][2] >= BF16_STAGE_SNR_DB["wav"] - 2.0 and float(wav16.abs().max()) <= 1.0
+
+
+# ---- a chunk's left context: rows nobody reads are not computed ------------------------------------------------------------
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_skipped_context_rows_leave_the_kept_samples_bit_identical_small(precision):
+    """q3c_forward_skip on the small architecture (partial tiles, the vector-path front end): the samples from
+    skip * total_upsample on equal q3c_forward's bit for bit, for skips of one frame, a few, a chunk's context and all but one;
+    chunked_decode (sibling :3686-3696: each chunk recomputes 25 context frames and drops their samples) gives the same
+    bits whether or not the context's rows are skipped, and matches the oracle as before."""
+    cfg = q3.tiny_config()
+    w = q3.synthetic_weights(cfg, seed=3)
+    dec = Decoder(cfg, w, device="cuda:0", precision=precision)
+    up = cfg.total_upsample
+    for B, T, skips in ((2, 40, (1, 3, 25, 39)), (1, 2, (1,)), (3, 101, (25,))):
+        codes = q3.random_codes(cfg, B, T, seed=T)
+        full = dec.forward(codes)
+        for k in skips:
+            part = dec.forward(codes, skip_frames=k)
+            assert part.shape == full.shape
+            assert torch.equal(part[..., k * up:], full[..., k * up:]), (precision, B, T, k)
+    with pytest.raises(ValueError):
+        dec.forward(q3.random_codes(cfg, 1, 4, seed=0), skip_frames=4)
+    codes = q3.random_codes(cfg, 2, 345, seed=9)
+    a = dec.chunked_decode(codes, 100, 25)
+    dec.skip_context = False
+    b = dec.chunked_decode(codes, 100, 25)
+    dec.skip_context = True
+    assert torch.equal(a, b)
+    if precision == "f32":
+        want = oracle.chunked_decode(cfg, w, codes, 100, 25)
+        assert max_abs(want, a) <= F32_MAX_ABS and snr_db(want, a) >= F32_SNR_DB
+    # decode() groups the (utterance, chunk) pieces by padded length AND context, so the launches' batch sizes - hence tile
+    # shapes and summation orders - differ from a run without skipping: judged against the oracle, not bit for bit
+    items = [q3.random_codes(cfg, 1, t, seed=t)[0] for t in (7, 130, 260, 101)]
+    got, sr = dec.decode(items, chunk_size=100, left_context_size=25)
+    assert sr == cfg.sample_rate
+    for item, x in zip(items, got):
+        want = oracle.chunked_decode(cfg, w, item[None], 100, 25)[0, 0].numpy()
+        assert x.shape == want.shape
+        if precision == "f32":
+            assert max_abs(want, x) <= F32_MAX_ABS and snr_db(want, x) >= F32_SNR_DB
+        else:       # (bf16 arithmetic is bounded by the tests above and in test_gpu_parity.py; here: every sample written)
+            assert np.isfinite(x).all() and np.abs(x).max() <= 1.0 and np.corrcoef(want, x)[0, 1] > 0.9
+    dec.close()
+
+
+def test_skipped_context_rows_flagship_bf16(flagship, flagship_bf16):
+    """The same at the flagship widths in bf16 (fused units on the raw stream, the folded final conv, the two-launch units of
+    the 768- and 384-channel blocks, 256-row tiles): a 100-frame chunk with 25 context frames, batch of 3."""
+    cfg, _w = flagship
+    dec = flagship_bf16
+    up = cfg.total_upsample
+    codes = q3.random_codes(cfg, 3, 100, seed=21)
+    full = dec.forward(codes)
+    part = dec.forward(codes, skip_frames=25)
+    assert torch.equal(part[..., 25 * up:], full[..., 25 * up:])
+    part = dec.forward(codes, skip_frames=99)
+    assert torch.equal(part[..., 99 * up:], full[..., 99 * up:])
+    codes = q3.random_codes(cfg, 2, 375, seed=22)
+    a = dec.chunked_decode(codes, cfg.chunk_size, cfg.left_context_size)
+    dec.skip_context = False
+    b = dec.chunked_decode(codes, cfg.chunk_size, cfg.left_context_size)
+    dec.skip_context = True
+    assert a.shape[-1] == cfg.chunked_output_length(375, cfg.chunk_size, cfg.left_context_size)
+    assert torch.equal(a, b)
