@@ -864,11 +864,14 @@ __global__ void __launch_bounds__(256) swa_attention_mfma_kernel(const bf16* __r
 // held in LDS; softmax by wave reductions in fp32; P.V: lane = dimension, the value rows read 128 bytes at a time.
 // Sums are explicit fma chains, but not in the tiled kernel's order: in fp32 the two agree to rounding (a few 1e-5 at the
 // waveform after the decoder's amplification), each within the fp32 bar of the reference decode.
-template <typename T>
+// D > 0: the head size as a compile-time constant (the loops over a row's pieces unroll, so a key's eight 16-byte pieces and
+// its rotation's table rows are all requested before the first product); D = 0: any head size.
+template <typename T, int D>
 __global__ void __launch_bounds__(256) swa_attention_step_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                                  const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                                  int nh, int nkv, int d, int window, float scale, int hist,
                                                                  const int* __restrict__ pos0, int max_pos, Q3KvRing ring) {
+    if (D > 0) d = D;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_att[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.x * 4 + wave, b = blockIdx.y;
@@ -907,14 +910,21 @@ __global__ void __launch_bounds__(256) swa_attention_step_kernel(const T* __rest
             const float* sr = sin_t + (size_t)ap * half;
             float alo = 0.f, ahi = 0.f;
             if (half % EPV == 0) {
+#pragma unroll
                 for (int e = 0; e < half; e += EPV) {
                     const uint4 klo = *(const uint4*)(kr + e), khi = *(const uint4*)(kr + e + half);
+                    float cc[EPV], ss[EPV];                 // table rows are 16-byte aligned (half % 4 == 0 here)
+#pragma unroll
+                    for (int u = 0; u < EPV; u += 4) {
+                        const float4 c4 = *(const float4*)(cr + e + u), s4 = *(const float4*)(sr + e + u);
+                        cc[u] = c4.x; cc[u + 1] = c4.y; cc[u + 2] = c4.z; cc[u + 3] = c4.w;
+                        ss[u] = s4.x; ss[u + 1] = s4.y; ss[u + 2] = s4.z; ss[u + 3] = s4.w;
+                    }
 #pragma unroll
                     for (int u = 0; u < EPV; ++u) {
                         const float x1 = q3_to_f32(((const T*)&klo)[u]), x2 = q3_to_f32(((const T*)&khi)[u]);
-                        const float cc = cr[e + u], ss = sr[e + u];
-                        alo = fmaf(Qs[e + u], x1 * cc - x2 * ss, alo);
-                        ahi = fmaf(Qs[e + u + half], x2 * cc + x1 * ss, ahi);
+                        alo = fmaf(Qs[e + u], x1 * cc[u] - x2 * ss[u], alo);
+                        ahi = fmaf(Qs[e + u + half], x2 * cc[u] + x1 * ss[u], ahi);
                     }
                 }
             } else {
@@ -943,6 +953,49 @@ __global__ void __launch_bounds__(256) swa_attention_step_kernel(const T* __rest
         if (64 * c < cnt) Ps[lane + 64 * c] = sc[c] * inv;
     __builtin_amdgcn_wave_barrier();
     const size_t vcol = (size_t)nkv * d + hk * d;
+    // P.V.  A value row is NP = d / EPV 16-byte pieces; when NP is a power of two <= 64 the wave's lanes form 64 / NP key groups
+    // of NP lanes: lane (g, piece) walks keys g, g + NG, ... with ONE 16-byte load per key, eight keys' loads in flight before
+    // their products are summed (a serial walk over the keys pays a memory round trip per key: 36 of them for a 72-frame
+    // window), and the groups' partial sums meet through lane exchanges.
+    const int NP = d / EPV;
+    if (d % EPV == 0 && NP <= 64 && (NP & (NP - 1)) == 0) {
+        const int NG = 64 / NP, g = lane / NP, piece = lane - g * NP;
+        float acc[EPV];
+#pragma unroll
+        for (int u = 0; u < EPV; ++u) acc[u] = 0.f;
+        const T* vnew = qrow + (size_t)(nh + nkv + hk) * d + piece * EPV;
+        const T* vring = ring_base + vcol + piece * EPV;
+        const int ring0 = jlo % hist;
+        constexpr int U = 8;
+        for (int j0 = 0; j0 < cnt; j0 += U * NG) {
+            uint4 v[U];
+            float pj[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int jj = j0 + u * NG + g;
+                const bool ok = jj < cnt;
+                int idx = ring0 + (ok ? jj : 0);
+                idx = idx >= hist ? idx - hist : idx;
+                const T* src = (!ok || jj == cnt - 1) ? vnew : vring + (size_t)idx * (2 * nkv * d);
+                v[u] = *(const uint4*)src;
+                pj[u] = ok ? Ps[jj] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int q = 0; q < EPV; ++q) acc[q] = fmaf(pj[u], q3_to_f32(((const T*)&v[u])[q]), acc[q]);
+        }
+        for (int off = NP; off < 64; off <<= 1)
+#pragma unroll
+            for (int q = 0; q < EPV; ++q) acc[q] += __shfl_xor(acc[q], off, 64);
+        if (g == 0) {
+            uint4 o;
+#pragma unroll
+            for (int q = 0; q < EPV; ++q) ((T*)&o)[q] = q3_from_f32<T>(acc[q]);
+            *(uint4*)(out + (size_t)b * (nh * d) + h * d + piece * EPV) = o;
+        }
+        return;
+    }
     for (int e = lane; e < d; e += 64) {
         float a0 = 0.f, a1 = 0.f;
         int idx = jlo % hist;
@@ -1152,12 +1205,11 @@ hipError_t q3_launch_swa_attention(const void* qkv, void* out, const float* cos_
         const size_t lds1 = (size_t)4 * (d + 64 * ATT_MAXC) * sizeof(float);
         dim3 grid1((nh + 3) / 4, B);
         const float scale1 = 1.0f / sqrtf((float)d);
-        if (dtype == Q3_BF16)
-            hipLaunchKernelGGL(swa_attention_step_kernel<bf16>, grid1, dim3(256), lds1, s, (const bf16*)qkv, (bf16*)out, cos_t, sin_t, nh, nkv, d,
-                               window, scale1, hist, pos0, max_pos, ring);
-        else
-            hipLaunchKernelGGL(swa_attention_step_kernel<float>, grid1, dim3(256), lds1, s, (const float*)qkv, (float*)out, cos_t, sin_t, nh, nkv,
-                               d, window, scale1, hist, pos0, max_pos, ring);
+#define Q3_STEP(TT, DD) hipLaunchKernelGGL((swa_attention_step_kernel<TT, DD>), grid1, dim3(256), lds1, s, (const TT*)qkv, (TT*)out, cos_t, sin_t, \
+                                           nh, nkv, d, window, scale1, hist, pos0, max_pos, ring)
+        if (dtype == Q3_BF16) { if (d == 64) Q3_STEP(bf16, 64); else Q3_STEP(bf16, 0); }
+        else { if (d == 64) Q3_STEP(float, 64); else Q3_STEP(float, 0); }
+#undef Q3_STEP
         return hipGetLastError();
     }
     if (dtype == Q3_BF16 && d == AM_D && hist == 0 && !pos0 && window >= 1 && window <= 257 && nkv > 0 && nh % nkv == 0 && !(q3_convgemm_tuning & 256)) {

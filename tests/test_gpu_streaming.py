@@ -70,6 +70,29 @@ def test_six_hundred_frames_one_frame_at_a_time():
     assert max_abs(got.cpu(), want) <= 1e-3 and snr_db(want, got.cpu()) >= 60.0
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_one_frame_pushes_at_head_size_64_with_grouped_heads(precision):
+    """The one-frame attention kernel at the flagship head size (its compile-time-sized form: 16-byte value pieces over key
+    groups, table rows fetched ahead), with grouped key/value heads, over more frames than the key ring holds (wrap-around):
+    fp32 against the oracle at the fp32 bar; bf16 against the library's bulk forward (which rounds the same operands)."""
+    cfg = q3.tiny_config("split_rvq", head_dim=64, num_attention_heads=4, num_key_value_heads=2, sliding_window=72)
+    dec, w = _decoder(cfg, precision=precision, seed=7)
+    T = 170
+    codes = q3.random_codes(cfg, 2, T, seed=11)
+    ref = dec.forward(codes)[:, 0]
+    pool = dec.open_streams(2)
+    ids = [pool.open(), pool.open()]
+    got = torch.cat([torch.stack(pool.push(ids, codes[:, :, t:t + 1].cuda())) for t in range(T)], dim=1)
+    assert got.shape == ref.shape
+    if precision == "f32":
+        want = oracle.forward(cfg, w, codes)[:, 0]
+        assert max_abs(got, ref) <= SAME_PATH_TOL, max_abs(got, ref)
+        assert max_abs(got.cpu(), want) <= 1e-3 and snr_db(want, got.cpu()) >= 60.0
+    else:       # two bf16 runs through different tile shapes: two noise realisations behind the amplifying blocks (measured 17.6 dB)
+        assert snr_db(ref, got) >= 14.0, snr_db(ref, got)
+    dec.close()
+
+
 def test_staggered_streams_share_launches():
     """Streams at different positions, joining and leaving, in changing order, with slot reuse."""
     cfg = q3.tiny_config("split_rvq")
