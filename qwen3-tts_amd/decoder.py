@@ -358,7 +358,7 @@ class Decoder:
         return one(encoded)
 
     def decode_device(self, encoded: CodesLike, chunk_size: Optional[int] = None, left_context_size: Optional[int] = None,
-                      pad_to: int = 25) -> Tuple[torch.Tensor, List[int], List[int]]:
+                      pad_to: Optional[int] = None) -> Tuple[torch.Tensor, List[int], List[int]]:
         """The decode of `decode` without the copy to the host: -> (flat float32 device tensor holding every
         utterance's samples back to back, start offset per utterance, length per utterance)."""
         cs = self.cfg.chunk_size if chunk_size is None else chunk_size
@@ -390,6 +390,15 @@ class Decoder:
                 o += int(c.shape[1])
         else:
             dev_items = [c.to(self.device) for c in items]
+        if pad_to is None:
+            # Padding frames are decoded for nothing.  With many pieces, finer buckets still fill their launches: take the
+            # finest of 25 / 10 / 5 / 1 frames that leaves the buckets 4096 frames on average (a fifth of a full launch)
+            total_frames = sum(e - s for _i, s, e, _c, _o in jobs)
+            pad_to = 25
+            for cand in (10, 5, 1):
+                nb = len({(-(-(e - s) // cand) * cand, ctx) for _i, s, e, ctx, _o in jobs})
+                if total_frames >= 4096 * nb:
+                    pad_to = cand
         buckets: Dict[Tuple[int, int], List[int]] = {}
         for j, (_i, s, e, ctx, _off) in enumerate(jobs):
             buckets.setdefault((-(-(e - s) // pad_to) * pad_to, ctx if self.skip_context else 0), []).append(j)
@@ -411,9 +420,10 @@ class Decoder:
         return out, starts, lengths
 
     def decode(self, encoded: CodesLike, chunk_size: Optional[int] = None, left_context_size: Optional[int] = None,
-               pad_to: int = 25) -> Tuple[List[np.ndarray], int]:
+               pad_to: Optional[int] = None) -> Tuple[List[np.ndarray], int]:
         """-> (list of float32 1-D numpy waveforms, 24000).  Utterances of different length are decoded together:
-        every (utterance, chunk) piece is padded with code 0 to a multiple of `pad_to` frames, pieces of equal padded
+        every (utterance, chunk) piece is padded with code 0 to a multiple of `pad_to` frames (None: 25, or finer when
+        there are enough pieces to fill finer buckets), pieces of equal padded
         length share a launch sequence, and each piece keeps only its own prefix of the output (a frame never
         influences samples that precede it by more than the fixed 555-sample lookahead)."""
         out, starts, lengths = self.decode_device(encoded, chunk_size, left_context_size, pad_to)
