@@ -251,7 +251,7 @@ def mixed_bench(args, cfg, weights, device, world, rank, distributed) -> dict:
     return {"metric": "audio-sec decoded/sec", "value": round(audio / elapsed, 1), "unit": "audio-sec/sec", "n_gpus": world,
             "steps": 1, "warmup": 1, "ms_per_step": round(elapsed * 1e3, 1), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"{len(items)} utterances of 2-30 s (seed 1234), pieces of equal length (padded to buckets of 25 frames, or finer when they still fill a launch) share launches, LPT-sharded over "
+            "config": {"workload": f"{len(items)} utterances of 2-30 s (seed 1234), pieces of equal length (padded to buckets of 25 frames, or 10 when those still fill a launch) share launches, LPT-sharded over "
                                    f"{world} rank(s), waveforms gathered to rank 0 and copied to host, flagship architecture",
                        "audio_seconds": round(audio, 1), "rank_load_imbalance": round(max(loads) / (sum(loads) / world), 4)}}
 

@@ -391,11 +391,12 @@ class Decoder:
         else:
             dev_items = [c.to(self.device) for c in items]
         if pad_to is None:
-            # Padding frames are decoded for nothing.  With many pieces, finer buckets still fill their launches: take the
-            # finest of 25 / 10 / 5 / 1 frames that leaves the buckets 4096 frames on average (a fifth of a full launch)
+            # Padding frames are decoded for nothing, but finer buckets mean more and smaller launches.  Measured on 2 000
+            # utterances of 2-30 s (tools/mixed_ab.py): 10-frame buckets 1.6 % faster than 25-frame ones, 5-frame ones 1 % slower.
+            # 10 frames when that leaves the buckets 4096 frames on average (a fifth of a full launch), else 25.
             total_frames = sum(e - s for _i, s, e, _c, _o in jobs)
             pad_to = 25
-            for cand in (10, 5, 1):
+            for cand in (10,):
                 nb = len({(-(-(e - s) // cand) * cand, ctx) for _i, s, e, ctx, _o in jobs})
                 if total_frames >= 4096 * nb:
                     pad_to = cand
@@ -422,8 +423,8 @@ class Decoder:
     def decode(self, encoded: CodesLike, chunk_size: Optional[int] = None, left_context_size: Optional[int] = None,
                pad_to: Optional[int] = None) -> Tuple[List[np.ndarray], int]:
         """-> (list of float32 1-D numpy waveforms, 24000).  Utterances of different length are decoded together:
-        every (utterance, chunk) piece is padded with code 0 to a multiple of `pad_to` frames (None: 25, or finer when
-        there are enough pieces to fill finer buckets), pieces of equal padded
+        every (utterance, chunk) piece is padded with code 0 to a multiple of `pad_to` frames (None: 25, or 10 when
+        there are enough pieces to fill the finer buckets), pieces of equal padded
         length share a launch sequence, and each piece keeps only its own prefix of the output (a frame never
         influences samples that precede it by more than the fixed 555-sample lookahead)."""
         out, starts, lengths = self.decode_device(encoded, chunk_size, left_context_size, pad_to)
