@@ -421,6 +421,21 @@ def main() -> None:
         host = dec._to_host(step())
     elapsed_d2h = (time.perf_counter() - t1) / psteps
     assert host.shape[0] == wav.numel()
+    # (c) the same step with every row of each chunk's left context computed (Decoder.skip_context off): the chunked decode as a
+    # loop of whole forwards would run it.  The samples are bit for bit the same (checked here on the first utterance).
+    ms_full_context = None
+    if not args.unchunked:
+        dec.skip_context = False
+        full = step()
+        torch.cuda.synchronize(device)
+        t2 = time.perf_counter()
+        for _ in range(psteps):
+            full = step()
+        torch.cuda.synchronize(device)
+        ms_full_context = (time.perf_counter() - t2) / psteps * 1e3
+        dec.skip_context = True
+        assert torch.equal(full[0], wav[0]), "skipping the dead context rows changed the samples"
+        del full
     expect = cfg.output_length(frames) if args.unchunked else cfg.chunked_output_length(frames)
     assert wav.shape == (args.batch, 1, expect), wav.shape
     assert bool(torch.isfinite(wav).all()) and float(wav.abs().max()) <= 1.0
@@ -464,7 +479,10 @@ def main() -> None:
                        "whole_path_frac_of_bf16_peak": round(whole / world / PEAK_BF16_TFLOPS, 4),
                        "gpu_event_ms_per_step": round(ev0.elapsed_time(ev1) / args.steps, 3),
                        "value_incl_d2h": round(args.batch * frames / cfg.frame_rate / elapsed_d2h, 1),
-                       "ms_per_step_incl_d2h": round(elapsed_d2h * 1e3, 3)},
+                       "ms_per_step_incl_d2h": round(elapsed_d2h * 1e3, 3),
+                       **({"dead_context_rows": "the conv-decoder rows under each later chunk's 25 dropped context frames are not "
+                                                "computed (q3c_forward_skip); samples bit-identical to whole forwards",
+                           "ms_per_step_with_context_rows_computed": round(ms_full_context, 3)} if ms_full_context else {})},
             "roofline": roof,
             "kernels": [{"kernel": p["kernel"], "launches": p["launches"] // psteps, "ms_per_step": round(p["ms"] / psteps, 3),
                          **({"tflops": round(p["flops"] / (p["ms"] * 1e-3) / 1e12, 1)} if p["flops"] else
