@@ -76,7 +76,7 @@ def pmc_traffic(variant: str):
     mang = {"f32": "f", "bf16": "DF16b"}
     # (rows, columns, waves, fused) -> the kernel template's wave grid and per-wave tile counts
     shapes = {("256", "96", "4", False): (4, 1, 2, 3), ("256", "128", "8", False): (4, 2, 2, 2), ("128", "128", "4", False): (2, 2, 2, 2),
-              ("256", "32", "4", False): (4, 1, 2, 1), ("256", "256", "8", False): (4, 2, 2, 4), ("256", "192", "8", False): (4, 2, 2, 3),
+              ("256", "32", "4", False): (4, 1, 2, 1), ("256", "64", "8", False): (8, 1, 1, 2), ("256", "256", "8", False): (4, 2, 2, 4), ("256", "192", "8", False): (4, 2, 2, 3),
               ("256", "192", "8", True): (4, 2, 2, 3), ("128", "192", "4", True): (2, 2, 2, 3), ("256", "96", "4", True): (4, 1, 2, 3), ("256", "32", "4", True): (4, 1, 2, 1)}
     sh = shapes.get((bm, bn, nw, bool(fused)))
     if sh is None:

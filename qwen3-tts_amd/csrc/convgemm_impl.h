@@ -1300,7 +1300,7 @@ hipError_t launch_cfg(const ConvGemmArgs& a_in, hipStream_t s) {
 
 // tile shapes (rows x columns, K-row bytes, waves)
 enum { SH_256x96 = 0, SH_256x128_K128, SH_128x128_K128, SH_128x128_K64, SH_256x32, SH_F_256x192, SH_F_256x96, SH_F_256x32,
-       SH_256x128_K64, SH_F_128x192, SH_F_128x384, SH_COUNT };
+       SH_256x128_K64, SH_F_128x192, SH_F_128x384, SH_256x64, SH_COUNT };
 
 int pick_shape(const ConvGemmArgs& a, size_t elem) {
     // rows that decide the shape: a launch that computes only the tail of its rows keeps the whole tensor's shape (the shape
@@ -1319,6 +1319,10 @@ int pick_shape(const ConvGemmArgs& a, size_t elem) {
     }
     const bool wide_k = ((size_t)a.K * elem) % 128 == 0;
     if (a.N <= 32 && a.act != Q3_ACT_SWIGLU) return SH_256x32;
+    // 33-64 columns over many rows (the encode side's 24 kHz and 12 kHz convs): exact 64-column tiles on eight waves of 32 rows
+    // x 64 columns, two blocks per CU.  Such layers are all prologue and epilogue (K = 32-128): in a 128-column tile half the
+    // columns are padding and the tile takes the general (bounds-checked) epilogue.
+    if (a.N > 32 && a.N <= 64 && a.act != Q3_ACT_SWIGLU && rows_all >= 8192 && !(q3_convgemm_tuning & 128)) return SH_256x64;
     const bool use_96 = (a.act != Q3_ACT_SWIGLU) && (a.N % 128 != 0) && (a.N % 96 == 0) && a.N < 512;
     if (use_96 && (a.N <= 96 || rows_all < 8192 || (q3_convgemm_tuning & 8))) return SH_256x96;     // larger N: more waves per CU beat exact tiling (memory-bound layers)
     if (!wide_k) return SH_128x128_K64;
@@ -1342,6 +1346,7 @@ hipError_t launch_typed(const ConvGemmArgs& a, hipStream_t s) {
         case SH_128x128_K64: return launch_cfg<TA, TO, 2, 2, 2, 2, 64, false>(a, s);
         case SH_256x32: return launch_cfg<TA, TO, 4, 1, 2, 1, 64, false>(a, s);
         case SH_256x128_K64: return launch_cfg<TA, TO, 4, 2, 2, 2, 64, false>(a, s);
+        case SH_256x64: return launch_cfg<TA, TO, 8, 1, 1, 2, 64, false>(a, s);
         default: break;
     }
     if constexpr (ALLOW_FUSE) {      // the fused form re-reads its input's element type as the residual: same-type pairs only
