@@ -382,40 +382,64 @@ class Decoder:
         out = torch.empty(total, dtype=torch.float32, device=self.device)
         if not items:
             return out, starts, lengths
+        flat_codes, bases = None, None
         if len(items) > 1 and all(c.device.type == "cpu" for c in items):      # one copy to the device, then views
-            flat_codes = torch.cat(items, dim=1).to(self.device)
-            dev_items, o = [], 0
+            # (a zero column at the end: the source of every padding frame when a launch's codes are gathered in one go)
+            flat_codes = torch.cat(items + [torch.zeros((Q, 1), dtype=torch.int64)], dim=1).to(self.device)
+            dev_items, bases, o = [], [], 0
             for c in items:
                 dev_items.append(flat_codes[:, o:o + int(c.shape[1])])
+                bases.append(o)
                 o += int(c.shape[1])
         else:
             dev_items = [c.to(self.device) for c in items]
+        # Launches: (padded length, context frames to skip, pieces).  Pieces of one launch share the context (its rows are
+        # skipped, forward's skip_frames) and are padded with code 0 to the launch's length.
+        launches: List[Tuple[int, int, List[int]]] = []
         if pad_to is None:
             # Padding frames are decoded for nothing, but finer buckets mean more and smaller launches.  Measured on 2 000
-            # utterances of 2-30 s (tools/mixed_ab.py): 10-frame buckets 1.6 % faster than 25-frame ones, 5-frame ones 1 % slower.
-            # 10 frames when that leaves the buckets 4096 frames on average (a fifth of a full launch), else 25.
+            # utterances of 2-30 s (tools/mixed_ab.py): 10-frame buckets 1.6 % faster than 25-frame ones, 5-frame ones 1 % slower;
+            # pieces sorted by length and cut into full launches of neighbours no faster than 25-frame buckets (a full launch
+            # of short pieces spans too many lengths).  10 frames when that leaves the buckets 4096 frames on average, else 25.
             total_frames = sum(e - s for _i, s, e, _c, _o in jobs)
-            pad_to = 25
-            for cand in (10,):
-                nb = len({(-(-(e - s) // cand) * cand, ctx) for _i, s, e, ctx, _o in jobs})
-                if total_frames >= 4096 * nb:
-                    pad_to = cand
+            nb10 = len({(-(-(e - s) // 10) * 10, ctx) for _i, s, e, ctx, _o in jobs})
+            pad_to = 10 if total_frames >= 4096 * nb10 else 25
         buckets: Dict[Tuple[int, int], List[int]] = {}
         for j, (_i, s, e, ctx, _off) in enumerate(jobs):
             buckets.setdefault((-(-(e - s) // pad_to) * pad_to, ctx if self.skip_context else 0), []).append(j)
         for (Lb, skip), idxs in sorted(buckets.items()):
             per = max(1, self.max_frames_per_launch // Lb)
             for i0 in range(0, len(idxs), per):
-                sub = idxs[i0:i0 + per]
+                launches.append((Lb, skip, idxs[i0:i0 + per]))
+        idx_dev, idx_off = None, []
+        if flat_codes is not None:
+            # every launch's gather indices built up front and copied to the device in ONE transfer: a blocking copy per launch
+            # would make the host wait for the launch before it, and the GPU for the host's next preparation
+            zero_col = int(flat_codes.shape[1]) - 1
+            total_idx = sum(len(sub) * Lb for Lb, _skip, sub in launches)
+            idx_all = np.full(total_idx, zero_col, dtype=np.int64)
+            o = 0
+            for Lb, _skip, sub in launches:
+                idx_off.append(o)
+                for n, j in enumerate(sub):
+                    i, s, e, _ctx, _off = jobs[j]
+                    idx_all[o + n * Lb: o + n * Lb + (e - s)] = np.arange(bases[i] + s, bases[i] + e)
+                o += len(sub) * Lb
+            idx_dev = torch.from_numpy(idx_all).to(self.device)
+        for k, (Lb, skip, sub) in enumerate(launches):
+            if idx_dev is not None:
+                idx = idx_dev[idx_off[k]: idx_off[k] + len(sub) * Lb].view(len(sub), Lb)
+                batch = flat_codes[:, idx].permute(1, 0, 2).contiguous()
+            else:
                 batch = torch.zeros((len(sub), Q, Lb), dtype=torch.int64, device=self.device)
                 for n, j in enumerate(sub):
                     i, s, e, _ctx, _off = jobs[j]
                     batch[n, :, : e - s] = dev_items[i][:, s:e]
-                wav = self.forward(batch, skip_frames=skip)
-                for n, j in enumerate(sub):
-                    i, s, e, ctx, off = jobs[j]
-                    keep = self.cfg.output_length(e - s) - ctx * up
-                    out[starts[i] + off: starts[i] + off + keep] = wav[n, 0, ctx * up: ctx * up + keep]
+            wav = self.forward(batch, skip_frames=skip)
+            for n, j in enumerate(sub):
+                i, s, e, ctx, off = jobs[j]
+                keep = self.cfg.output_length(e - s) - ctx * up
+                out[starts[i] + off: starts[i] + off + keep] = wav[n, 0, ctx * up: ctx * up + keep]
         with torch.cuda.device(self.device):
             self._check(self._lib.q3c_check_errors(self._ctx, self._stream()))
         return out, starts, lengths
