@@ -180,9 +180,9 @@ class Decoder:
     # ------------------------------------------------------------------------------------------------
     def forward(self, codes: torch.Tensor, check_codes: bool = False, skip_frames: int = 0) -> torch.Tensor:
         """codes [B, Q, T] int64 -> wav [B, 1, T*1920 - 555] float32 on the device, clamped to [-1, 1].
-        skip_frames > 0 (a chunk's left context, q3c_forward_skip): the samples of the first skip_frames frames are left
-        unwritten and the rows of the conv decoder that only they depend on are not computed; the other samples are bit
-        for bit those of skip_frames = 0."""
+        skip_frames > 0 (a chunk's left context, q3c_forward_skip): the samples of the first skip_frames frames come back as
+        zeros and the rows of the conv decoder that only they depend on are not computed; the other samples are bit for
+        bit those of skip_frames = 0."""
         codes = self._codes_tensor(codes)
         B, _, T = codes.shape
         if T < 1 or B < 1:
@@ -195,6 +195,7 @@ class Decoder:
             ws = self._workspace(B, T)
             base = (ws.data_ptr() + 255) // 256 * 256
             if skip_frames:
+                wav[..., : skip_frames * self.cfg.total_upsample].zero_()      # the library leaves them unwritten
                 self._check(self._lib.q3c_forward_skip(self._ctx, C.c_void_p(codes.data_ptr()), B, T, skip_frames,
                                                        C.c_void_p(wav.data_ptr()), C.c_void_p(base),
                                                        ws.numel() - (base - ws.data_ptr()), self._stream()))

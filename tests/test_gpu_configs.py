@@ -479,6 +479,7 @@ def test_skipped_context_rows_leave_the_kept_samples_bit_identical_small(precisi
             part = dec.forward(codes, skip_frames=k)
             assert part.shape == full.shape
             assert torch.equal(part[..., k * up:], full[..., k * up:]), (precision, B, T, k)
+            assert not bool(part[..., : k * up].any())          # the dropped samples come back as zeros, not as stale memory
     with pytest.raises(ValueError):
         dec.forward(q3.random_codes(cfg, 1, 4, seed=0), skip_frames=4)
     codes = q3.random_codes(cfg, 2, 345, seed=9)
@@ -502,6 +503,21 @@ def test_skipped_context_rows_leave_the_kept_samples_bit_identical_small(precisi
             assert max_abs(want, x) <= F32_MAX_ABS and snr_db(want, x) >= F32_SNR_DB
         else:       # (bf16 arithmetic is bounded by the tests above and in test_gpu_parity.py; here: every sample written)
             assert np.isfinite(x).all() and np.abs(x).max() <= 1.0 and np.corrcoef(want, x)[0, 1] > 0.9
+    dec.close()
+
+
+def test_skipped_context_rows_wide_blocks_fp32():
+    """fp32 at the flagship's conv-decoder widths (768 / 384 / 192-channel blocks run their units as two launches in fp32, each
+    with its own first row; the k = 1 conv must not fold the batch into its rows then)."""
+    cfg = q3.tiny_config("split_rvq", decoder_dim=1536)
+    w = q3.synthetic_weights(cfg, seed=5)
+    dec = Decoder(cfg, w, device="cuda:0", precision="f32")
+    up = cfg.total_upsample
+    codes = q3.random_codes(cfg, 2, 31, seed=4)
+    full = dec.forward(codes)
+    for k in (25, 30):
+        part = dec.forward(codes, skip_frames=k)
+        assert torch.equal(part[..., k * up:], full[..., k * up:]), k
     dec.close()
 
 
