@@ -328,6 +328,8 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--seconds", type=float, default=30.0)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-context-check", action="store_true",
+                    help="leave out the extra steps that compute every context row (profiler runs: one kind of step per process)")
     ap.add_argument("--unchunked", action="store_true", help="one forward over all frames instead of chunked_decode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=3, help="utterances in the CPU baseline sample")
@@ -424,7 +426,7 @@ def main() -> None:
     # (c) the same step with every row of each chunk's left context computed (Decoder.skip_context off): the chunked decode as a
     # loop of whole forwards would run it.  The samples are bit for bit the same (checked here on the first utterance).
     ms_full_context = None
-    if not args.unchunked:
+    if not args.unchunked and not args.no_context_check:
         dec.skip_context = False
         full = step()
         torch.cuda.synchronize(device)
