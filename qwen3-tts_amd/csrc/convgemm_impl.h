@@ -1300,7 +1300,7 @@ hipError_t launch_cfg(const ConvGemmArgs& a_in, hipStream_t s) {
 
 // tile shapes (rows x columns, K-row bytes, waves)
 enum { SH_256x96 = 0, SH_256x128_K128, SH_128x128_K128, SH_128x128_K64, SH_256x32, SH_F_256x192, SH_F_256x96, SH_F_256x32,
-       SH_256x128_K64, SH_F_128x192, SH_F_128x384, SH_256x64, SH_COUNT };
+       SH_256x128_K64, SH_F_128x192, SH_F_128x384, SH_256x64, SH_128x32_K128, SH_128x64_K128, SH_COUNT };
 
 int pick_shape(const ConvGemmArgs& a, size_t elem) {
     // rows that decide the shape: a launch that computes only the tail of its rows keeps the whole tensor's shape (the shape
@@ -1332,6 +1332,15 @@ int pick_shape(const ConvGemmArgs& a, size_t elem) {
     if (!(q3_convgemm_tuning & 2) && rows_all >= 8192) return SH_256x128_K64;
     // Few rows (a streaming push, a short utterance): 128-row tiles on four waves double the number of blocks when
     // 256-row tiles would leave most of the 256 CUs idle (256 streams x 1 frame: push 5.75 -> 5.46 ms)
+    // A frame-rate push (a few hundred rows): with 128-column tiles a 1024-column layer is 16 workgroups, each streaming its
+    // 128 weight rows from HBM through ONE CU's DMA path (12-17 B per cycle): the layer takes what that path takes.  32-column
+    // tiles put four times as many CUs on the weights; the rows they all re-read (256 x K) come from L2.
+    const long long tiles128 = ((rows_all + 127) / 128) * ((a.N + 127) / 128);
+    // (SwiGLU pairs adjacent 32-column tiles inside a wave: 64-column tiles there)
+    if (rows_all <= 1024 && a.N >= 256 && a.N % 64 == 0 && !(q3_convgemm_tuning & 32)) {
+        if (a.act != Q3_ACT_SWIGLU && tiles128 < 128) return SH_128x32_K128;
+        if (a.act == Q3_ACT_SWIGLU && tiles128 < 256) return SH_128x64_K128;
+    }
     const long long tiles256 = ((rows_all + 255) / 256) * ((a.N + 127) / 128);
     const bool small = tiles256 < 512;
     return (small != ((q3_convgemm_tuning & 1) != 0)) ? SH_128x128_K128 : SH_256x128_K128;
@@ -1347,6 +1356,8 @@ hipError_t launch_typed(const ConvGemmArgs& a, hipStream_t s) {
         case SH_256x32: return launch_cfg<TA, TO, 4, 1, 2, 1, 64, false>(a, s);
         case SH_256x128_K64: return launch_cfg<TA, TO, 4, 2, 2, 2, 64, false>(a, s);
         case SH_256x64: return launch_cfg<TA, TO, 8, 1, 1, 2, 64, false>(a, s);
+        case SH_128x32_K128: return launch_cfg<TA, TO, 4, 1, 1, 1, 128, false>(a, s);
+        case SH_128x64_K128: return launch_cfg<TA, TO, 4, 1, 1, 2, 128, false>(a, s);
         default: break;
     }
     if constexpr (ALLOW_FUSE) {      // the fused form re-reads its input's element type as the residual: same-type pairs only
