@@ -332,11 +332,47 @@ __global__ void __launch_bounds__(256) rmsnorm_kernel(const T* __restrict__ x, c
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
     const T* xr = x + row * H;
+    T* yr = y + row * H;
+    constexpr int EPV = 16 / (int)sizeof(T);
+    // rows of up to 64 x EPV x 4 elements in 16-byte pieces: the row is read ONCE, all of a lane's pieces requested before the
+    // first is used (a frame-rate push runs 17 of these on 256 rows each: what they cost is their chain of memory round trips)
+    if (H % EPV == 0 && H <= 64 * EPV * 4) {
+        const int np = H / EPV;                                 // pieces per row
+        uint4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int pc = lane + 64 * k;
+            v[k] = pc < np ? *(const uint4*)(xr + pc * EPV) : make_uint4(0, 0, 0, 0);
+        }
+        float ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) { const float f = q3_to_f32(((const T*)&v[k])[e]); ss += f * f; }
+        ss = wave_sum(ss);
+        const float r = rsqrtf(ss / (float)H + eps);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int pc = lane + 64 * k;
+            if (pc < np) {
+                uint4 o;
+#pragma unroll
+                for (int e = 0; e < EPV; e += 4) {
+                    const float4 w4 = *(const float4*)(w + pc * EPV + e);
+                    ((T*)&o)[e] = q3_from_f32<T>(w4.x * (q3_to_f32(((const T*)&v[k])[e]) * r));
+                    ((T*)&o)[e + 1] = q3_from_f32<T>(w4.y * (q3_to_f32(((const T*)&v[k])[e + 1]) * r));
+                    ((T*)&o)[e + 2] = q3_from_f32<T>(w4.z * (q3_to_f32(((const T*)&v[k])[e + 2]) * r));
+                    ((T*)&o)[e + 3] = q3_from_f32<T>(w4.w * (q3_to_f32(((const T*)&v[k])[e + 3]) * r));
+                }
+                *(uint4*)(yr + pc * EPV) = o;
+            }
+        }
+        return;
+    }
     float ss = 0.f;
     for (int i = lane; i < H; i += 64) { float v = q3_to_f32(xr[i]); ss += v * v; }
     ss = wave_sum(ss);
     const float r = rsqrtf(ss / (float)H + eps);
-    T* yr = y + row * H;
     for (int i = lane; i < H; i += 64) yr[i] = q3_from_f32<T>(w[i] * (q3_to_f32(xr[i]) * r));
 }
 
