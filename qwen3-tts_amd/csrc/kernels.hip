@@ -911,8 +911,8 @@ __global__ void __launch_bounds__(256) swa_attention_step_kernel(const T* __rest
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_att[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.x * 4 + wave, b = blockIdx.y;
-    if (h >= nh) return;                                   // waves are independent: no barrier below
-    const int hk = h / (nh / nkv), half = d >> 1;
+    const bool live = h < nh;                              // (every wave reaches the one barrier below)
+    const int hk = (live ? h : nh - 1) / (nh / nkv), half = d >> 1;
     const int p = pos0[b];                                 // the query's frame number
     const int rs = (nh + 2 * nkv) * d;
     const T* qrow = qkv + (size_t)b * rs;
@@ -920,18 +920,46 @@ __global__ void __launch_bounds__(256) swa_attention_step_kernel(const T* __rest
     const T* ring_base = (const T*)(ring.state + (long long)slot * ring.slot_stride + ring.state_off);
     float* Qs = (float*)smem_att + (size_t)wave * (d + 64 * ATT_MAXC);
     float* Ps = Qs + d;
+    const int jlo = max(max(0, p - hist), p - window + 1);      // oldest frame the ring still holds and the window allows
+    const int cnt = p - jlo + 1;
+    // The rotation tables' rows of frames jlo .. p, staged once for the block's four heads (row stride half + 1: lane = key
+    // reads hit distinct banks).  Read per lane from global memory they were twice the keys' traffic, 16 bytes of every
+    // line a request touches.
+    const int tld = half + 1;
+    float* Cs = (float*)smem_att + (size_t)4 * (d + 64 * ATT_MAXC);
+    float* Ss = Cs + (size_t)window * tld;
+    if (half % 4 == 0) {
+        const int q4 = half >> 2;
+        for (int i = tid; i < cnt * q4; i += 256) {
+            const int r = i / q4, e = (i - r * q4) * 4;
+            const size_t src = (size_t)min(jlo + r, max_pos - 1) * half + e;
+            const float4 c4 = *(const float4*)(cos_t + src), s4 = *(const float4*)(sin_t + src);
+            float* cd = Cs + r * tld + e;
+            float* sd = Ss + r * tld + e;
+            cd[0] = c4.x; cd[1] = c4.y; cd[2] = c4.z; cd[3] = c4.w;
+            sd[0] = s4.x; sd[1] = s4.y; sd[2] = s4.z; sd[3] = s4.w;
+        }
+    } else {
+        for (int i = tid; i < cnt * half; i += 256) {
+            const int r = i / half, e = i - r * half;
+            const size_t src = (size_t)min(jlo + r, max_pos - 1) * half + e;
+            Cs[r * tld + e] = cos_t[src];
+            Ss[r * tld + e] = sin_t[src];
+        }
+    }
+    __syncthreads();
+    if (!live) return;
     {
-        const int ap = min(p, max_pos - 1);
+        const float* cq = Cs + (cnt - 1) * tld;
+        const float* sq = Ss + (cnt - 1) * tld;
         for (int e = lane; e < half; e += 64) {
             const float x1 = q3_to_f32(qrow[h * d + e]), x2 = q3_to_f32(qrow[h * d + e + half]);
-            const float c = cos_t[(size_t)ap * half + e], sn = sin_t[(size_t)ap * half + e];
+            const float c = cq[e], sn = sq[e];
             Qs[e] = x1 * c - x2 * sn;
             Qs[e + half] = x2 * c + x1 * sn;
         }
     }
     __builtin_amdgcn_wave_barrier();
-    const int jlo = max(max(0, p - hist), p - window + 1);      // oldest frame the ring still holds and the window allows
-    const int cnt = p - jlo + 1;
     constexpr int EPV = 16 / (int)sizeof(T);
     float sc[ATT_MAXC];
     float mx = -INFINITY;
@@ -941,26 +969,19 @@ __global__ void __launch_bounds__(256) swa_attention_step_kernel(const T* __rest
         const int j = jlo + lane + 64 * c;
         if (64 * c < cnt && j <= p) {
             const T* kr = (j == p) ? qrow + (nh + hk) * d : ring_base + (size_t)(j % hist) * (2 * nkv * d) + hk * d;
-            const int ap = min(j, max_pos - 1);
-            const float* cr = cos_t + (size_t)ap * half;
-            const float* sr = sin_t + (size_t)ap * half;
+            const float* cr = Cs + (j - jlo) * tld;
+            const float* sr = Ss + (j - jlo) * tld;
             float alo = 0.f, ahi = 0.f;
             if (half % EPV == 0) {
 #pragma unroll
                 for (int e = 0; e < half; e += EPV) {
                     const uint4 klo = *(const uint4*)(kr + e), khi = *(const uint4*)(kr + e + half);
-                    float cc[EPV], ss[EPV];                 // table rows are 16-byte aligned (half % 4 == 0 here)
-#pragma unroll
-                    for (int u = 0; u < EPV; u += 4) {
-                        const float4 c4 = *(const float4*)(cr + e + u), s4 = *(const float4*)(sr + e + u);
-                        cc[u] = c4.x; cc[u + 1] = c4.y; cc[u + 2] = c4.z; cc[u + 3] = c4.w;
-                        ss[u] = s4.x; ss[u + 1] = s4.y; ss[u + 2] = s4.z; ss[u + 3] = s4.w;
-                    }
 #pragma unroll
                     for (int u = 0; u < EPV; ++u) {
                         const float x1 = q3_to_f32(((const T*)&klo)[u]), x2 = q3_to_f32(((const T*)&khi)[u]);
-                        alo = fmaf(Qs[e + u], x1 * cc[u] - x2 * ss[u], alo);
-                        ahi = fmaf(Qs[e + u + half], x2 * cc[u] + x1 * ss[u], ahi);
+                        const float cc = cr[e + u], ss = sr[e + u];
+                        alo = fmaf(Qs[e + u], x1 * cc - x2 * ss, alo);
+                        ahi = fmaf(Qs[e + u + half], x2 * cc + x1 * ss, ahi);
                     }
                 }
             } else {
@@ -1238,15 +1259,21 @@ hipError_t q3_launch_swa_attention(const void* qkv, void* out, const float* cos_
     Q3KvRing ring{};
     if (ring_in) ring = *ring_in;
     if (T == 1 && hist > 0) {          // a frame-rate push: one wave per (stream, head)
-        const size_t lds1 = (size_t)4 * (d + 64 * ATT_MAXC) * sizeof(float);
+        const size_t lds1 = ((size_t)4 * (d + 64 * ATT_MAXC) + (size_t)2 * window * (d / 2 + 1)) * sizeof(float);   // + the staged table rows
+        if (lds1 > 160 * 1024) return hipErrorInvalidValue;
         dim3 grid1((nh + 3) / 4, B);
         const float scale1 = 1.0f / sqrtf((float)d);
-#define Q3_STEP(TT, DD) hipLaunchKernelGGL((swa_attention_step_kernel<TT, DD>), grid1, dim3(256), lds1, s, (const TT*)qkv, (TT*)out, cos_t, sin_t, \
-                                           nh, nkv, d, window, scale1, hist, pos0, max_pos, ring)
-        if (dtype == Q3_BF16) { if (d == 64) Q3_STEP(bf16, 64); else Q3_STEP(bf16, 0); }
-        else { if (d == 64) Q3_STEP(float, 64); else Q3_STEP(float, 0); }
-#undef Q3_STEP
-        return hipGetLastError();
+        auto step = [&](auto kern, auto* qp, auto* op) -> hipError_t {
+            if (lds1 > 48 * 1024) {
+                hipError_t ea = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+                if (ea != hipSuccess) return ea;
+            }
+            hipLaunchKernelGGL(kern, grid1, dim3(256), lds1, s, qp, op, cos_t, sin_t, nh, nkv, d, window, scale1, hist, pos0, max_pos, ring);
+            return hipGetLastError();
+        };
+        if (dtype == Q3_BF16)
+            return d == 64 ? step(swa_attention_step_kernel<bf16, 64>, (const bf16*)qkv, (bf16*)out) : step(swa_attention_step_kernel<bf16, 0>, (const bf16*)qkv, (bf16*)out);
+        return d == 64 ? step(swa_attention_step_kernel<float, 64>, (const float*)qkv, (float*)out) : step(swa_attention_step_kernel<float, 0>, (const float*)qkv, (float*)out);
     }
     if (dtype == Q3_BF16 && d == AM_D && hist == 0 && !pos0 && window >= 1 && window <= 257 && nkv > 0 && nh % nkv == 0 && !(q3_convgemm_tuning & 256)) {
         const bool wide = window > 97;             // nine key tiles per wave instead of four
