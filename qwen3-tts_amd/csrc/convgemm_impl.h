@@ -1232,7 +1232,8 @@ convgemm_kernel(const ConvGemmArgs p) {
 
 // ---- host side ----------------------------------------------------------------------------------------
 // A/B switches for measurements (q3_convgemm_tuning, defined in convgemm.hip): bit 0 flips the 128- / 256-row choice for
-// layers of few rows, bit 1 = one block per CU (128-byte K rows) for large layers, bit 2 = the fused 192-channel unit on
+// layers of few rows and keeps 64-byte K rows for layers of at most one tile per CU, bit 5 = no narrow tiles for frame-rate pushes,
+// bit 7 = no 64-column tiles, bit 1 = one block per CU (128-byte K rows) for large layers, bit 2 = the fused 192-channel unit on
 // 256-row tiles, bit 3 = exact 96-column tiling for the 288-column transposed conv; bits 8.. go to the kernel as
 // ConvGemmArgs::debug
 
@@ -1329,7 +1330,14 @@ int pick_shape(const ConvGemmArgs& a, size_t elem) {
     // Layers with enough rows to fill the chip: 256x128 tiles with 64-byte K rows need 65-73 KB of LDS, so TWO blocks
     // (16 waves) share a CU and one block's prologue, barriers and epilogue hide under the other's MFMAs (measured against one 129-KB block with
     // 128-byte rows: k = 7 convs +6..14 %, k = 1 convs +36..49 %, transposed convs +6..19 %).
-    if (!(q3_convgemm_tuning & 2) && rows_all >= 8192) return SH_256x128_K64;
+    if (!(q3_convgemm_tuning & 2) && rows_all >= 8192) {
+        // At most one tile per CU (a frame-rate push's first block): a second block per CU has nothing to overlap with, and the
+        // launch takes what one tile's chain of steps takes - 128-byte K rows halve the steps (k = 7 conv of 768 channels over
+        // 9 700 rows: 128 -> 100 us).
+        const long long t256 = ((rows_all + 255) / 256) * ((a.N + 127) / 128);
+        if (!(q3_convgemm_tuning & 1) && t256 <= 256) return SH_256x128_K128;
+        return SH_256x128_K64;
+    }
     // Few rows (a streaming push, a short utterance): 128-row tiles on four waves double the number of blocks when
     // 256-row tiles would leave most of the 256 CUs idle (256 streams x 1 frame: push 5.75 -> 5.46 ms)
     // A frame-rate push (a few hundred rows): with 128-column tiles a 1024-column layer is 16 workgroups, each streaming its
