@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(256) rvq_encode_kernel(const float* __restrict
             float best[RVQ_FT];
             int besti[RVQ_FT];
 #pragma unroll
-            for (int f = 0; f < RVQ_FT; ++f) { best[f] = INFINITY; besti[f] = 0x7fffffff; }
+            for (int f = 0; f < RVQ_FT; ++f) { best[f] = INFINITY; besti[f] = 0; }      // NaN / Inf frames score no row below INFINITY: row 0, as argmin
             const float4* tt = tables_t[q];                // dimension-major copy: consecutive codes are consecutive float4s
             for (int c = tid; c < bins; c += 256) {
                 float acc[RVQ_FT];
@@ -126,6 +126,7 @@ __global__ void __launch_bounds__(256) rvq_encode_kernel(const float* __restrict
                     const int oi = bi[w2 * RVQ_FT + tid];
                     if (ov < v || (ov == v && oi < ix)) { v = ov; ix = oi; }
                 }
+                ix = min(max(ix, 0), bins - 1);            // the residual update indexes the table with it: never out of range
                 win[tid] = ix;
                 if (tid < nf) {
                     const long long fr = f0 + tid, b = fr / T, t = fr - b * T;
@@ -214,7 +215,7 @@ __global__ void __launch_bounds__(256) rvq_encode_mfma_kernel(const float* __res
 #pragma unroll
             for (int s2 = 0; s2 < D / 2; ++s2) breg[s2] = R[fr_l * RLD + 8 * (s2 >> 2) + 4 * hh + (s2 & 3)];
             float best = INFINITY;
-            int besti = 0x7fffffff;
+            int besti = 0;                                 // a NaN / Inf frame scores no row below INFINITY and keeps row 0 (what argmin returns)
             // The table pieces of a tile are fetched eight at a time (32 k-steps), one group ahead of the group being multiplied,
             // also across tiles; every index below is a compile-time constant so that breg stays in registers.
             constexpr int NG = D / 64;                     // groups of eight 16-byte pieces (32 k-steps) per tile: D / 2 k-steps in all
@@ -272,6 +273,7 @@ __global__ void __launch_bounds__(256) rvq_encode_mfma_kernel(const float* __res
                     const int oi = bi[w2 * RVQM_FT + tid];
                     if (ov < v || (ov == v && oi < ix)) { v = ov; ix = oi; }
                 }
+                ix = min(max(ix, 0), bins - 1);            // the residual update indexes the table with it: never out of range
                 win[tid] = ix;
                 if (tid < nf) {
                     const long long fr = f0 + tid, b = fr / T, t = fr - b * T;

@@ -9,6 +9,7 @@ libq3c.so (hand-written gfx950 kernels); torch is used for device memory and str
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import Dict, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
@@ -28,9 +29,21 @@ def rope_inv_freq(cfg: DecoderConfig) -> torch.Tensor:
     return 1.0 / (cfg.rope_theta ** (torch.arange(0, d, 2, dtype=torch.float) / d))
 
 
-_STAGE: Dict[int, tuple] = {}          # device index -> (two pinned staging buffers, two events)
+_STAGE: Dict[int, tuple] = {}          # device index -> (two pinned staging buffers, two events, a lock)
+_STAGE_GUARD = threading.Lock()
+_STAGE_PIECE = 128 << 20               # bytes per staging buffer
 _COPY_THREADS = 4
 _copy_pool = None
+
+
+def _stage_buffers(dev: torch.device) -> tuple:
+    """The device's pinned staging buffers, events and the lock that serialises their users (two threads copying out on one
+    GPU - a batcher worker beside a gather, two decoders - would otherwise overwrite each other's pieces)."""
+    with _STAGE_GUARD:
+        if dev.index not in _STAGE:
+            _STAGE[dev.index] = ([torch.empty(_STAGE_PIECE, dtype=torch.uint8, pin_memory=True) for _ in range(2)],
+                                 [torch.cuda.Event() for _ in range(2)], threading.Lock())
+        return _STAGE[dev.index]
 
 
 def _parallel_copy(dst: np.ndarray, src: np.ndarray) -> None:
@@ -66,15 +79,14 @@ def to_host(flat: torch.Tensor) -> np.ndarray:
     bytes_dev = flat.view(torch.uint8)
     res_b = res.view(np.uint8)
     nb = int(bytes_dev.numel())
-    piece = 128 << 20                                   # bytes per staging buffer
+    piece = _STAGE_PIECE
     dev = flat.device
-    if dev.index not in _STAGE:
-        _STAGE[dev.index] = ([torch.empty(piece, dtype=torch.uint8, pin_memory=True) for _ in range(2)],
-                             [torch.cuda.Event() for _ in range(2)])
-    stage, stage_ev = _STAGE[dev.index]
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    stage, stage_ev, lock = _stage_buffers(dev)
     stream = torch.cuda.current_stream(dev)
     bounds = [(a, min(a + piece, nb)) for a in range(0, nb, piece)]
-    with torch.cuda.device(dev):
+    with lock, torch.cuda.device(dev):
         for k, (a, b) in enumerate(bounds[:2]):
             stage[k][: b - a].copy_(bytes_dev[a:b], non_blocking=True)
             stage_ev[k].record(stream)
@@ -127,6 +139,34 @@ class Decoder:
                 shape = (C.c_int64 * t.dim())(*t.shape)
                 self._check(self._lib.q3c_load_weight(self._ctx, name.encode(), C.c_void_p(t.data_ptr()), shape, t.dim()))
             self._check(self._lib.q3c_finalize(self._ctx))
+
+    @classmethod
+    def from_local(cls, path: str, device: Union[str, torch.device] = "cuda:0", precision: str = "bf16",
+                   rename: Optional[Dict[str, str]] = None, **kwargs) -> "Decoder":
+        """A decoder from a LOCAL checkpoint directory (config.json + *.safetensors; see checkpoint.load_local): the local-path
+        half of `Qwen3TTSModel.from_pretrained(model_path, ...)` (reference models.py:43-48) for the decoder alone.  A hub name
+        or any path that is not a directory here raises FileNotFoundError; nothing is ever downloaded."""
+        from .checkpoint import load_local
+        cfg, w = load_local(path, rename)
+        return cls(cfg, w, device=device, precision=precision, **kwargs)
+
+    def warmup(self, batch: int = 1, frames: int = 25, stream_pool: Optional["StreamPool"] = None, streams: int = 0,
+               frames_per_push: int = 1) -> float:
+        """Take every first-use cost out of the first request, as the reference's warm-up generation does for its compiled model
+        (reference models.py:68-106): one decode of `batch` x `frames` random codes (loads the code object, sets the kernels'
+        LDS attributes, allocates the workspace and the pinned host staging buffers) and, with a stream pool, one graph-replayed
+        push of `streams` x `frames_per_push` on scratch slots (plan, descriptor table, graph instantiation).  -> seconds."""
+        import time
+        t0 = time.time()
+        g = torch.Generator().manual_seed(0)
+        codes = torch.randint(0, self.cfg.codebook_size, (batch, self.cfg.num_quantizers, frames), generator=g, dtype=torch.int64)
+        self.decode([c for c in codes])
+        with torch.cuda.device(self.device):
+            _stage_buffers(self.device)
+        if stream_pool is not None and streams > 0:
+            stream_pool.warmup(streams, frames_per_push)
+        torch.cuda.synchronize(self.device)
+        return time.time() - t0
 
     # ------------------------------------------------------------------------------------------------
     def _check(self, rc: int) -> None:

@@ -161,6 +161,37 @@ def test_rvq_encode_full_size_round_trip():
     assert full < first < 1.0
 
 
+@pytest.mark.parametrize("size", ["tiny", "full"])
+def test_rvq_encode_non_finite_frames_keep_codes_in_range(size):
+    """A NaN or Inf embedding (non-finite reference audio) scores no code-book row below the starting INFINITY: both search
+    kernels (vector ALU for small books, matrix op for 2048 x 256) must then return an in-range code - row 0, as argmin over
+    an all-NaN row does - and must not index the table with a sentinel.  The finite frames beside them keep their codes."""
+    if size == "tiny":
+        cfg, din = q3.tiny_config(), q3.tiny_config().codebook_dim
+        w = q3.synthetic_weights(cfg, seed=3)
+    else:
+        cfg, din = q3.tiny_config(codebook_size=2048, num_quantizers=16, codebook_dim=256, rvq_out_dim=512), 512
+        w = q3.synthetic_weights(cfg, seed=3)
+        g = torch.Generator().manual_seed(5)
+        for grp in ("semantic", "acoustic"):
+            w[f"quantizer.{grp}.input_proj.weight"] = torch.randn(256, 512, 1, generator=g) * (512 ** -0.5) * 3.0
+    dec = _decoder(cfg, w, "f32")
+    emb = torch.randn(1, 40, din, generator=torch.Generator().manual_seed(9))
+    clean = dec.rvq_encode(emb).cpu()
+    bad = emb.clone()
+    bad[0, 3] = float("nan")
+    bad[0, 17, 0] = float("inf")
+    bad[0, 33] = float("-inf")
+    got = dec.rvq_encode(bad).cpu()
+    torch.cuda.synchronize()
+    assert int(got.min()) >= 0 and int(got.max()) < cfg.codebook_size
+    assert bool((got[0, :, 3] == 0).all()) and bool((got[0, :, 33] == 0).all())
+    keep = [t for t in range(40) if t not in (3, 17, 33)]
+    assert torch.equal(got[0][:, keep], clean[0][:, keep])
+    # the decode direction still runs on those codes
+    assert torch.isfinite(dec.rvq_dequant(got.cuda())).all()
+
+
 # ---- single operators against the sibling fixtures ------------------------------------------------------
 @pytest.mark.parametrize("precision,atol", [("f32", 2e-5), ("bf16", 6e-2)])
 def test_operators_vs_golden(golden, precision, atol):
