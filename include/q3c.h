@@ -219,6 +219,20 @@ typedef struct q3c_profile_entry {
 int q3c_profile_enable(q3c_ctx* ctx, int32_t on);   /* 0 off, 1 per kernel, 2 per (kernel, layer shape) */
 int q3c_profile_read(q3c_ctx* ctx, q3c_profile_entry* out, int32_t capacity, int32_t* count);
 
+/* -- measurement aids (no counterpart in the reference; used by tools/ and by parity tests that compare two kernels for one
+ *    operation).  Both are state of ONE context: other contexts in the process are not affected. -------------------------
+ * q3c_debug_set_tuning: switches that make the following launches of this context choose another tile shape or kernel than
+ * the default (0).  Bits 0-7, 16-19: tile-shape choices of the contraction kernel (csrc/convgemm_impl.h); 64: the 384-channel
+ * residual unit as one launch; 256: the vector-ALU attention kernel for every case; 512: the final conv as its own launch;
+ * 1 << 20: the vector-ALU code-book search.  Every choice computes the same operation.
+ * q3c_debug_set_timeline: every 64th workgroup of this context's contraction launches stores clock values at its phase
+ * boundaries into dev_buffer (8 x int64 per slot); NULL switches it off. */
+int q3c_debug_set_tuning(q3c_ctx* ctx, int32_t bits);
+int q3c_debug_set_timeline(q3c_ctx* ctx, long long* dev_buffer, int32_t slots);
+/* The same two settings for the TEMPORARY contexts the single-operator entry points below build per call (they take no
+ * context argument); contexts made by q3c_create never read them. */
+int q3c_debug_set_operator_context(int32_t tuning, long long* timeline_dev, int32_t slots);
+
 /* -- single operators (host weights in the PyTorch layout are repacked and uploaded per call: meant for
  *    operator-level parity tests and integration bring-up, not for the serving loop; they synchronise) ------
  * x / y are DEVICE fp32, channels-last.  precision picks the MFMA operand type as in q3c_config. */

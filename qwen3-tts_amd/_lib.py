@@ -23,7 +23,8 @@ EXPORTS = ["q3c_create", "q3c_destroy", "q3c_last_error", "q3c_version", "q3c_lo
            "q3c_set_tap", "q3c_causal_conv1d", "q3c_causal_tconv1d", "q3c_snake_beta", "q3c_profile_enable",
            "q3c_profile_read", "q3c_stream_pool_create", "q3c_stream_pool_destroy", "q3c_stream_state_bytes",
            "q3c_stream_reset", "q3c_stream_workspace_bytes", "q3c_stream_push", "q3c_stream_push_graph", "q3c_residual_unit", "q3c_convnext_block",
-           "q3c_transformer", "q3c_wav_to_pcm16", "q3c_encoder_configure", "q3c_encode_frames", "q3c_encode_workspace_bytes", "q3c_encode"]
+           "q3c_transformer", "q3c_wav_to_pcm16", "q3c_encoder_configure", "q3c_encode_frames", "q3c_encode_workspace_bytes", "q3c_encode",
+           "q3c_debug_set_tuning", "q3c_debug_set_timeline", "q3c_debug_set_operator_context"]
 
 
 class Q3cProfileEntry(C.Structure):
@@ -123,6 +124,9 @@ def load() -> C.CDLL:
     lib.q3c_transformer.argtypes = [vp, vp, i32, i32, vp, vp, C.c_size_t, vp]
     lib.q3c_wav_to_pcm16.argtypes = [vp, C.c_int64, vp, vp]
     lib.q3c_profile_enable.argtypes = [vp, i32]
+    lib.q3c_debug_set_tuning.argtypes = [vp, i32]
+    lib.q3c_debug_set_timeline.argtypes = [vp, vp, i32]
+    lib.q3c_debug_set_operator_context.argtypes = [i32, vp, i32]
     lib.q3c_profile_read.argtypes = [vp, C.POINTER(Q3cProfileEntry), i32, C.POINTER(i32)]
     lib.q3c_stream_pool_create.argtypes = [vp, i32, C.POINTER(vp)]
     lib.q3c_stream_pool_destroy.argtypes = [vp]
@@ -140,10 +144,6 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         if name not in ("q3c_destroy", "q3c_last_error", "q3c_version", "q3c_stream_pool_destroy"):
             fn.restype = C.c_int
-    if os.environ.get("Q3C_TUNING"):          # measurement aid: A/B switches of the contraction kernel's shape choice
-        lib.q3c_debug_set_tuning.argtypes = [C.c_int]
-        lib.q3c_debug_set_tuning.restype = None
-        lib.q3c_debug_set_tuning(int(os.environ["Q3C_TUNING"]))
     _lib = lib
     return lib
 

@@ -52,7 +52,9 @@ struct ConvGemmArgs {
                                                          // P rows of 8 floats), which q3_launch_tap_sum then sums along the diagonal
     int nxb;                                             // input buffers in LDS (2 or 3): set by the launcher
     int tile_order;                                      // 0: N tile slowest, 1: N tile fastest, G >= 2: N tiles in groups of G (set by the launcher)
-    int debug;                                           // measurement aid: bit 4 = plain (not XCD-grouped) tile order
+    int tuning;                                          // the context's measurement switches (0 = defaults; q3c_debug_set_tuning): shape choices read
+                                                         // bits 0-7 and 16-20 on the host, bits 8.. reach the kernel as `debug`
+    int debug;                                           // measurement aid: bit 4 = plain (not XCD-grouped) tile order (set by the launcher)
     const void* zeros;                                   // >= 16 bytes of zeros in device memory (source of out-of-sequence rows)
     int row_lo;                                          // 0, or negative: X points |row_lo| rows INTO a sequence whose earlier rows exist
                                                          // and are read as the halo (a launch that computes the sequence's tail only)
@@ -66,8 +68,7 @@ enum Q3Dtype : int { Q3_F32 = 0, Q3_BF16 = 1 };
 // ---- launchers (each returns hipError_t of the launch) -------------------------------------------
 hipError_t q3_launch_convgemm(const ConvGemmArgs& a, int in_dtype, int out_dtype, hipStream_t s);
 const char* q3_convgemm_variant(const ConvGemmArgs& a, int in_dtype, int out_dtype);   // name of the instantiation that would run
-int q3_convgemm_fusable(int N, int dtype);                     // can a residual unit of N channels run as one fused launch?
-void q3_convgemm_set_tuning(int bits);               // A/B switches for measurements (0 = defaults)
+int q3_convgemm_fusable(int N, int dtype, int tuning = 0);     // can a residual unit of N channels run as one fused launch?
 
 hipError_t q3_launch_rvq_gather_sum(const long long* codes, int B, int Q, int T, int bins, int D,
                                     const float* const* tables_dev /*[Q] device array of table pointers*/,
@@ -77,7 +78,7 @@ hipError_t q3_launch_rvq_gather_sum(const long long* codes, int B, int Q, int T,
 // tables_t_dev: per code book a dimension-major copy [D/4][bins] of float4, followed by the rows' squared norms [bins]
 hipError_t q3_launch_rvq_encode(const float* emb, int B, int T, int in_dim, int Q, int bins, int D, const float* const* tables_dev,
                                 const void* const* tables_t_dev, const int* group_start_dev, int G, const float* in_proj_dev,
-                                long long* codes, hipStream_t s);
+                                long long* codes, hipStream_t s, int tuning = 0 /* bit 20: the vector-ALU search */);
 hipError_t q3_launch_mean_embedding(const long long* codes, int B, int Q, int T, int bins, int H,
                                     const float* table, void* out, int out_dtype, int* err_flag, hipStream_t s);
 // y[b, m] = act(bias + sum_t P[b, m - (taps - 1) + t, t]) over the rows m - (taps - 1) + t >= 0: the one-channel causal conv
@@ -101,7 +102,8 @@ struct Q3KvRing { const char* state; long long slot_stride, state_off; const int
 // `ring`, and pos0[b] is the frame number of item b's query 0 (null: 0)
 hipError_t q3_launch_swa_attention(const void* qkv, void* out, const float* cos_t, const float* sin_t, int B, int T,
                                    int nh, int nkv, int d, int window, int dtype, hipStream_t s, int hist = 0,
-                                   const int* pos0 = nullptr, int max_pos = 1 << 30, const Q3KvRing* ring = nullptr);
+                                   const int* pos0 = nullptr, int max_pos = 1 << 30, const Q3KvRing* ring = nullptr,
+                                   int tuning = 0 /* bit 8: the vector-ALU kernel for every case */);
 
 // one carried tensor of the streaming decode; offsets and strides in bytes, all multiples of 16
 struct Q3CarryDesc {

@@ -2,8 +2,6 @@
 // its own translation unit (convgemm_<in>_<out>.hip) so that the kernel instantiations compile in parallel.
 #include "convgemm_impl.h"
 
-int q3_convgemm_tuning = 0;
-
 hipError_t q3_convgemm_f32_f32(const ConvGemmArgs& a, hipStream_t s);
 hipError_t q3_convgemm_bf16_bf16(const ConvGemmArgs& a, hipStream_t s);
 hipError_t q3_convgemm_f32_bf16(const ConvGemmArgs& a, hipStream_t s);
@@ -13,13 +11,7 @@ hipError_t q3_convgemm_bf16_f32(const ConvGemmArgs& a, hipStream_t s);
 // 384 channels fit one launch too (shape "resunit 128x384"), but measured equal to the two-launch unit in bulk (22.1 ms
 // against 14.9 + 6.4 ms per 64 x 300 frames: eight waves at one block per CU run the contraction at 0.77 of the
 // unfused 7-tap conv's rate) and 2 % slower for frame-rate pushes, so it stays behind tuning bit 64.
-int q3_convgemm_fusable(int N, int dtype) { return N <= (dtype == Q3_BF16 ? ((q3_convgemm_tuning & 64) ? 384 : 192) : 96); }
-void q3_convgemm_set_tuning(int bits) { q3_convgemm_tuning = bits; }
-extern "C" void q3c_debug_set_tuning(int bits) { q3_convgemm_tuning = bits; }   // measurement aid (tools/): not part of include/q3c.h
-// measurement aid (tools/timeline.py): phase timestamps of every 64th workgroup of the launches that follow
-static long long* q3_timeline = nullptr;
-static int q3_timeline_slots = 0;
-extern "C" void q3c_debug_set_timeline(long long* dev_buffer, int slots) { q3_timeline = dev_buffer; q3_timeline_slots = slots; }
+int q3_convgemm_fusable(int N, int dtype, int tuning) { return N <= (dtype == Q3_BF16 ? ((tuning & 64) ? 384 : 192) : 96); }
 
 const char* q3_convgemm_variant(const ConvGemmArgs& a, int in_dtype, int out_dtype) {
     static const char* shapes[SH_COUNT] = {"256x96,k64B,4w", "256x128,k128B,8w", "128x128,k128B,4w", "128x128,k64B,4w", "256x32,k64B,4w",
@@ -36,8 +28,7 @@ const char* q3_convgemm_variant(const ConvGemmArgs& a, int in_dtype, int out_dty
 
 hipError_t q3_launch_convgemm(const ConvGemmArgs& a_in, int in_dtype, int out_dtype, hipStream_t s) {
     ConvGemmArgs a = a_in;
-    a.debug = q3_convgemm_tuning >> 8;
-    a.timeline = q3_timeline; a.timeline_slots = q3_timeline_slots;
+    a.debug = a.tuning >> 8;
     if (a.M <= 0 || a.B <= 0) return hipSuccess;
     const int epc_in = in_dtype == Q3_BF16 ? 8 : 4;
     if (a.K % epc_in || a.ldx % epc_in || a.x_batch_stride % epc_in || a.taps < 1 || a.off_step < 0)

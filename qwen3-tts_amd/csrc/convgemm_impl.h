@@ -32,8 +32,6 @@
 #include <cstdio>
 #include <type_traits>
 
-extern int q3_convgemm_tuning;
-
 namespace {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -1231,7 +1229,7 @@ convgemm_kernel(const ConvGemmArgs p) {
 }
 
 // ---- host side ----------------------------------------------------------------------------------------
-// A/B switches for measurements (q3_convgemm_tuning, defined in convgemm.hip): bit 0 flips the 128- / 256-row choice for
+// A/B switches for measurements (ConvGemmArgs::tuning, the context's word): bit 0 flips the 128- / 256-row choice for
 // layers of few rows and keeps 64-byte K rows for layers of at most one tile per CU, bit 5 = no narrow tiles for frame-rate pushes,
 // bit 7 = no 64-column tiles, bit 1 = one block per CU (128-byte K rows) for large layers, bit 2 = the fused 192-channel unit on
 // 256-row tiles, bit 3 = exact 96-column tiling for the 288-column transposed conv; bits 8.. go to the kernel as
@@ -1262,14 +1260,14 @@ hipError_t launch_cfg(const ConvGemmArgs& a_in, hipStream_t s) {
         // ones: N tiles in groups (their weights resident, the input once per group; pairs measured against N tile slowest:
         // transposed conv 768 -> 5 x 384 +8.5 %, k = 7 conv of 768 channels +0.8 %).  Tuning bit 16 = N tile slowest.
         if (wbytes <= (5LL << 19)) a.tile_order = 1;
-        else if (::q3_convgemm_tuning & 16) a.tile_order = 0;
+        else if (a.tuning & 16) a.tile_order = 0;
         else {
             // group size: as many N tiles as keep their weight slices within ~3 MB of the XCD's 4 MB L2 (at least a pair),
             // evened out over the groups (transposed conv 768 -> 5 x 384: groups of 5 against pairs +6 %)
             const long long slice = (long long)a.taps * BN * a.K * sizeof(TA);
             const int n_tiles = (a.N + BN - 1) / BN;
             int gmax = (int)((3LL << 20) / slice);
-            if ((::q3_convgemm_tuning >> 16) & 15) gmax = (::q3_convgemm_tuning >> 16) & 15;
+            if ((a.tuning >> 16) & 15) gmax = (a.tuning >> 16) & 15;
             gmax = gmax < 2 ? 2 : gmax;
             const int groups = (n_tiles + gmax - 1) / gmax;
             const int g = (n_tiles + groups - 1) / groups;
@@ -1312,7 +1310,7 @@ int pick_shape(const ConvGemmArgs& a, size_t elem) {
         if (a.N <= 96) return SH_F_256x96;       // (128-row tiles, three blocks per CU: measured 9 % slower)
         // 128-row tiles on four waves keep the unit's LDS under 80 KB: two independent blocks per CU, one's h tile and
         // epilogue under the other's MFMAs, against one 8-wave block in lockstep
-        if (a.N <= 192) return (elem == 2 && !(q3_convgemm_tuning & 4)) ? SH_F_128x192 : SH_F_256x192;
+        if (a.N <= 192) return (elem == 2 && !(a.tuning & 4)) ? SH_F_128x192 : SH_F_256x192;
         // 384 channels (bf16): 128 rows x 384 columns on eight waves, one block per CU; the whole first-contraction weight
         // (2 MB) is re-streamed from L2 per 128 rows, which the matrix pipe's time per tile still covers
         if (a.N <= 384 && elem == 2) return SH_F_128x384;
@@ -1323,19 +1321,19 @@ int pick_shape(const ConvGemmArgs& a, size_t elem) {
     // 33-64 columns over many rows (the encode side's 24 kHz and 12 kHz convs): exact 64-column tiles on eight waves of 32 rows
     // x 64 columns, two blocks per CU.  Such layers are all prologue and epilogue (K = 32-128): in a 128-column tile half the
     // columns are padding and the tile takes the general (bounds-checked) epilogue.
-    if (a.N > 32 && a.N <= 64 && a.act != Q3_ACT_SWIGLU && rows_all >= 8192 && !(q3_convgemm_tuning & 128)) return SH_256x64;
+    if (a.N > 32 && a.N <= 64 && a.act != Q3_ACT_SWIGLU && rows_all >= 8192 && !(a.tuning & 128)) return SH_256x64;
     const bool use_96 = (a.act != Q3_ACT_SWIGLU) && (a.N % 128 != 0) && (a.N % 96 == 0) && a.N < 512;
-    if (use_96 && (a.N <= 96 || rows_all < 8192 || (q3_convgemm_tuning & 8))) return SH_256x96;     // larger N: more waves per CU beat exact tiling (memory-bound layers)
+    if (use_96 && (a.N <= 96 || rows_all < 8192 || (a.tuning & 8))) return SH_256x96;     // larger N: more waves per CU beat exact tiling (memory-bound layers)
     if (!wide_k) return SH_128x128_K64;
     // Layers with enough rows to fill the chip: 256x128 tiles with 64-byte K rows need 65-73 KB of LDS, so TWO blocks
     // (16 waves) share a CU and one block's prologue, barriers and epilogue hide under the other's MFMAs (measured against one 129-KB block with
     // 128-byte rows: k = 7 convs +6..14 %, k = 1 convs +36..49 %, transposed convs +6..19 %).
-    if (!(q3_convgemm_tuning & 2) && rows_all >= 8192) {
+    if (!(a.tuning & 2) && rows_all >= 8192) {
         // At most one tile per CU (a frame-rate push's first block): a second block per CU has nothing to overlap with, and the
         // launch takes what one tile's chain of steps takes - 128-byte K rows halve the steps (k = 7 conv of 768 channels over
         // 9 700 rows: 128 -> 100 us).
         const long long t256 = ((rows_all + 255) / 256) * ((a.N + 127) / 128);
-        if (!(q3_convgemm_tuning & 1) && t256 <= 256) return SH_256x128_K128;
+        if (!(a.tuning & 1) && t256 <= 256) return SH_256x128_K128;
         return SH_256x128_K64;
     }
     // Few rows (a streaming push, a short utterance): 128-row tiles on four waves double the number of blocks when
@@ -1345,13 +1343,13 @@ int pick_shape(const ConvGemmArgs& a, size_t elem) {
     // tiles put four times as many CUs on the weights; the rows they all re-read (256 x K) come from L2.
     const long long tiles128 = ((rows_all + 127) / 128) * ((a.N + 127) / 128);
     // (SwiGLU pairs adjacent 32-column tiles inside a wave: 64-column tiles there)
-    if (rows_all <= 1024 && a.N >= 256 && a.N % 64 == 0 && !(q3_convgemm_tuning & 32)) {
+    if (rows_all <= 1024 && a.N >= 256 && a.N % 64 == 0 && !(a.tuning & 32)) {
         if (a.act != Q3_ACT_SWIGLU && tiles128 < 128) return SH_128x32_K128;
         if (a.act == Q3_ACT_SWIGLU && tiles128 < 256) return SH_128x64_K128;
     }
     const long long tiles256 = ((rows_all + 255) / 256) * ((a.N + 127) / 128);
     const bool small = tiles256 < 512;
-    return (small != ((q3_convgemm_tuning & 1) != 0)) ? SH_128x128_K128 : SH_256x128_K128;
+    return (small != ((a.tuning & 1) != 0)) ? SH_128x128_K128 : SH_256x128_K128;
 }
 
 template <typename TA, typename TO, bool ALLOW_FUSE>

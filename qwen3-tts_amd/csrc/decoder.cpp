@@ -16,8 +16,6 @@
 // device and everything after that goes through the pointer it returned.
 static __device__ __align__(256) unsigned char q3c_static_scratch[Q3C_STATIC_SCRATCH_BYTES];
 
-extern int q3_convgemm_tuning;      // measurement switches (convgemm.hip); bit 512 here: the final conv as its own launch
-
 namespace {
 
 struct HostTensor { std::vector<int64_t> shape; std::vector<float> data; };
@@ -99,6 +97,11 @@ struct q3c_ctx {
     // per-kernel timing
     struct ProfRec { hipEvent_t a, b; const char* name; double flops, bytes; };
     bool fuse_units = true;           // residual units of <= 192 channels as one launch
+    int tuning = 0;                   // measurement switches of THIS context (q3c_debug_set_tuning; 0 = defaults): tile-shape choices
+                                      // (ConvGemmArgs::tuning), bit 256 the vector-ALU attention, bit 512 the final conv as its own
+                                      // launch, bit 1 << 20 the vector-ALU code-book search
+    long long* timeline = nullptr;    // measurement aid (q3c_debug_set_timeline): phase timestamps of every 64th workgroup
+    int timeline_slots = 0;
     bool profiling = false, profile_detail = false;
     std::set<std::string> interned;
     std::vector<ProfRec> prof;
@@ -316,6 +319,7 @@ int gemm(q3c_ctx* c, const GemmW& g, const void* X, int B, int L_in, void* Y, in
     a.Y2 = o.Y2; a.y2_batch_stride = a.y_batch_stride;
     a.zeros = c->zero_page;
     a.row_start = o.row_start;
+    a.tuning = c->tuning; a.timeline = c->timeline; a.timeline_slots = c->timeline_slots;
     if (o.second) {
         if (!o.pre) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "fused residual unit without its input SnakeBeta");
         a.W2 = o.second->w; a.bias2 = o.second->bias; a.pre_a = o.pre->a; a.pre_invb = o.pre->invb;
@@ -456,7 +460,7 @@ int transformer_stack(q3c_ctx* c, int B, int T, void* bufA, void* bufB, char* bu
         TRY(gemm(c, y.qkv, nrm, B, T, qkv, T, dt, GemmOpts{}, s));
         LAUNCH_B(c, s, "swa_attention", fr * (size_t)(2 * qd + 2 * kvd) * es,
                  q3_launch_swa_attention(qkv, att, c->cos_t, c->sin_t, B, T, k.num_attention_heads, k.num_key_value_heads, k.head_dim,
-                                         k.sliding_window, dt, s));
+                                         k.sliding_window, dt, s, 0, nullptr, 1 << 30, nullptr, c->tuning));
         GemmOpts o1; o1.scale = y.ls_attn; o1.R = x;
         TRY(gemm(c, y.o, att, B, T, x, T, dt, o1, s));
         LAUNCH_B(c, s, "rmsnorm", 2 * fr * H * es, q3_launch_rmsnorm(x, y.ln2, nrm, (long long)fr, H, k.rms_norm_eps, dt, s));
@@ -521,7 +525,7 @@ int validate_config(q3c_ctx* c) {
 // convs of the un-chunked forward see there) and the first `trim` samples of the first push are blank.
 // =========================================================================================================
 // a captured push: the launch sequence of one (S, n) with these exact operand addresses baked into its kernel nodes
-struct PushGraph { const void *slots, *codes, *wav, *ws; hipGraphExec_t exec; };
+struct PushGraph { const void *slots, *codes, *wav, *ws; int tuning; bool fuse; hipGraphExec_t exec; unsigned long long used; };
 struct StreamPlan {
     size_t ws_bytes = 0; Q3CarryDesc* descs = nullptr; int ndesc = 0; std::vector<PushGraph> graphs;
     double carried_bytes = 0, appended_bytes = 0;      // per stream: rows copied in and out around a push; rows appended to rings
@@ -539,6 +543,7 @@ struct q3c_stream_pool {
     std::map<std::pair<int, int>, StreamPlan> plans;
     std::vector<void*> allocs;
     hipStream_t capture_stream = nullptr;   // side stream the push graphs are captured on (the legacy default stream cannot capture)
+    unsigned long long graph_clock = 0;     // replay counter: least-recently-used eviction of cached graphs
 };
 
 namespace {
@@ -641,7 +646,7 @@ int stream_sequence(q3c_stream_pool* P, int S, int n, bool run, const StreamPlan
         Q3KvRing ring{P->state, P->slot_stride, ring_off, slots, P->capacity};
         LAUNCH_B(c, s, "swa_attention", fr * (size_t)(2 * qd + 2 * kvd) * es,
                  q3_launch_swa_attention(ptr(qkv), ws + o_att, c->cos_t, c->sin_t, S, n, k.num_attention_heads, k.num_key_value_heads,
-                                         k.head_dim, k.sliding_window, dt, s, ring_rows, pos0, k.max_positions, &ring));
+                                         k.head_dim, k.sliding_window, dt, s, ring_rows, pos0, k.max_positions, &ring, c->tuning));
         GemmOpts o1; o1.scale = y.ls_attn; o1.R = x;
         TRY(gemm(c, y.o, ws + o_att, S, n, x, n, dt, o1, s));
         LAUNCH_B(c, s, "rmsnorm", 2 * fr * H * es, q3_launch_rmsnorm(x, y.ln2, nrm, (long long)fr, H, k.rms_norm_eps, dt, s));
@@ -702,7 +707,7 @@ int stream_sequence(q3c_stream_pool* P, int S, int n, bool run, const StreamPlan
         const int Lr = L * b.rate;
         const int* rs_t = rs_all + (size_t)(2 * i) * S;
         const int* rs_u = rs_all + (size_t)(2 * i + 1) * S;
-        const bool fuse = c->fuse_units && q3_convgemm_fusable(ch, dt);
+        const bool fuse = c->fuse_units && q3_convgemm_fusable(ch, dt, c->tuning);
         // unfused units keep a raw residual stream beside the snaked tensors and an h tensor between their two convs;
         // fused units read and write the raw stream only (their [carried | new] tensors ARE the residual stream)
         const size_t o_raw = fuse ? 0 : alloc((size_t)S * Lr * ch * es);
@@ -792,7 +797,7 @@ int stream_plan(q3c_stream_pool* P, int S, int n, StreamPlan** out, bool create)
 // =========================================================================================================
 extern "C" {
 
-const char* q3c_version(void) { return "q3c 0.1 (gfx950)"; }
+const char* q3c_version(void) { return "q3c 0.2 (gfx950)"; }
 
 int q3c_create(const q3c_config* cfg, q3c_ctx** out) {
     if (!cfg || !out) return Q3C_ERR_INVALID_ARGUMENT;
@@ -1090,7 +1095,7 @@ int q3c_rvq_encode(q3c_ctx* c, const float* emb, int32_t B, int32_t T, int32_t i
                                                      std::to_string(want) + (c->rvq_in_proj ? " (its input_proj)" : " (no input_proj was loaded)"));
     LAUNCH(c, q3_launch_rvq_encode(emb, B, T, in_dim, c->cfg.num_quantizers, c->cfg.codebook_size, c->cfg.codebook_dim, c->tables_dev,
                                    (const void* const*)c->tables_t_dev, c->group_start_dev, c->G, c->rvq_in_proj, (long long*)codes,
-                                   (hipStream_t)stream));
+                                   (hipStream_t)stream, c->tuning));
     return 0;
 }
 
@@ -1233,14 +1238,14 @@ static int forward_impl(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, 
     const auto last_tap = c->taps.find(Q3C_STAGE_BLOCK0 + (int)c->blocks.size() - 1);
     // (a tap on the last block's output needs that tensor in memory; the fold needs one column tile to hold every channel)
     const bool fold_final = c->conv_out_fold && c->fuse_units && dt == Q3_BF16 && (ch_last == 96 || ch_last == 32) && c->conv_out.taps <= 8 &&
-                            (last_tap == c->taps.end() || !last_tap->second.first) && !(q3_convgemm_tuning & 512);
+                            (last_tap == c->taps.end() || !last_tap->second.first) && !(c->tuning & 512);
     for (size_t i = 0; i < c->blocks.size(); ++i) {
         const Block& b = c->blocks[i];
         if (L < 2) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "sequence too short for the transposed convolutions");
         const int Lq = L - 1;
         ch /= 2;
         void* raw = free_bufs[0]; void* sn = free_bufs[1]; void* sp = free_bufs[2];
-        const bool fuse = c->fuse_units && q3_convgemm_fusable(ch, dt);
+        const bool fuse = c->fuse_units && q3_convgemm_fusable(ch, dt, c->tuning);
         {
             // fused units read the raw stream and apply their own first SnakeBeta: the transposed conv then writes ONE tensor
             GemmOpts g; g.row0 = tconv_row0[i];
@@ -1283,6 +1288,19 @@ static int forward_impl(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, 
         GemmOpts g; g.act = Q3_ACT_CLAMP; g.row0 = out_row0;
         TRY(gemm(c, c->conv_out, cur, B, L, wav, L, Q3_F32, g, s));
     }
+    return 0;
+}
+
+// measurement aids: per context, never process-wide (two contexts in one process keep their own settings)
+int q3c_debug_set_tuning(q3c_ctx* c, int32_t bits) {
+    if (!c) return Q3C_ERR_INVALID_ARGUMENT;
+    c->tuning = bits;
+    return 0;
+}
+
+int q3c_debug_set_timeline(q3c_ctx* c, long long* dev_buffer, int32_t slots) {
+    if (!c || slots < 0) return Q3C_ERR_INVALID_ARGUMENT;
+    c->timeline = dev_buffer; c->timeline_slots = dev_buffer ? slots : 0;
     return 0;
 }
 
@@ -1403,13 +1421,23 @@ int q3c_stream_push_graph(q3c_stream_pool* P, const int32_t* slots, int32_t S, c
     // per-kernel profiling records events between launches, and a caller who is capturing already gets the plain sequence
     if (c->profiling || !c->taps.empty() || st != hipStreamCaptureStatusNone)
         return stream_sequence(P, S, n, true, pl, slots, codes, wav, (char*)ws, s, nullptr, nullptr, nullptr);
-    for (const PushGraph& g : pl->graphs)
-        if (g.slots == slots && g.codes == codes && g.wav == wav && g.ws == ws) {
+    // a graph replays the launch sequence it recorded: besides the four buffers the key holds what chooses that sequence
+    for (PushGraph& g : pl->graphs)
+        if (g.slots == slots && g.codes == codes && g.wav == wav && g.ws == ws && g.tuning == c->tuning && g.fuse == c->fuse_units) {
+            g.used = ++P->graph_clock;
             HIPCHK(c, hipGraphLaunch(g.exec, s));
             return 0;
         }
-    if (pl->graphs.size() >= MAX_GRAPHS_PER_PLAN)       // a caller that never reuses its buffers gains nothing from graphs
-        return stream_sequence(P, S, n, true, pl, slots, codes, wav, (char*)ws, s, nullptr, nullptr, nullptr);
+    // A caller whose workspace moved (it grew) can never present the old address again: those graphs are dead weight.
+    for (size_t i = 0; i < pl->graphs.size();)
+        if (pl->graphs[i].ws != ws) { (void)hipGraphExecDestroy(pl->graphs[i].exec); pl->graphs.erase(pl->graphs.begin() + (long)i); }
+        else ++i;
+    if (pl->graphs.size() >= MAX_GRAPHS_PER_PLAN) {     // full: the least recently replayed combination makes room
+        size_t lru = 0;
+        for (size_t i = 1; i < pl->graphs.size(); ++i) if (pl->graphs[i].used < pl->graphs[lru].used) lru = i;
+        (void)hipGraphExecDestroy(pl->graphs[lru].exec);
+        pl->graphs.erase(pl->graphs.begin() + (long)lru);
+    }
     if (!P->capture_stream) HIPCHK(c, hipStreamCreateWithFlags(&P->capture_stream, hipStreamNonBlocking));
     HIPCHK(c, hipStreamBeginCapture(P->capture_stream, hipStreamCaptureModeThreadLocal));
     const int rc = stream_sequence(P, S, n, true, pl, slots, codes, wav, (char*)ws, P->capture_stream, nullptr, nullptr, nullptr);
@@ -1417,7 +1445,7 @@ int q3c_stream_push_graph(q3c_stream_pool* P, const int32_t* slots, int32_t S, c
     const hipError_t e = hipStreamEndCapture(P->capture_stream, &graph);
     if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     if (e != hipSuccess || !graph) return fail(c, Q3C_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-    PushGraph pg{slots, codes, wav, ws, nullptr};
+    PushGraph pg{slots, codes, wav, ws, c->tuning, c->fuse_units, nullptr, ++P->graph_clock};
     const hipError_t e2 = hipGraphInstantiate(&pg.exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     if (e2 != hipSuccess) return fail(c, Q3C_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e2));
@@ -1427,6 +1455,18 @@ int q3c_stream_push_graph(q3c_stream_pool* P, const int32_t* slots, int32_t S, c
 }
 
 // ---- single operators ---------------------------------------------------------------------------------------
+// The operator entry points below build a temporary context per call.  Measurement switches for THOSE contexts only (tools/
+// and tests that compare two kernels for one operator); contexts made by q3c_create never read them.
+static int op_tuning = 0;
+static long long* op_timeline = nullptr;
+static int op_timeline_slots = 0;
+static void operator_defaults(q3c_ctx* c) { c->tuning = op_tuning; c->timeline = op_timeline; c->timeline_slots = op_timeline_slots; }
+int q3c_debug_set_operator_context(int32_t tuning, long long* timeline_dev, int32_t slots) {
+    if (slots < 0) return Q3C_ERR_INVALID_ARGUMENT;
+    op_tuning = tuning; op_timeline = timeline_dev; op_timeline_slots = timeline_dev ? slots : 0;
+    return 0;
+}
+
 static int op_run(GemmW& g, q3c_ctx* c, const float* x, int B, int L_in, int cin, float* y, int M, int n_out, int precision,
                   hipStream_t s) {
     const int dt = precision == Q3C_PRECISION_BF16 ? Q3_BF16 : Q3_F32;
@@ -1452,6 +1492,7 @@ int q3c_causal_conv1d(const float* x, int32_t B, int32_t L, int32_t cin, int32_t
                       const float* bias, float* y, int32_t precision, void* stream) {
     if (!x || !w || !y || B < 1 || L < 1 || cin % 8 || cout < 1 || k < 1 || dil < 1) return Q3C_ERR_INVALID_ARGUMENT;
     q3c_ctx tmp;
+    operator_defaults(&tmp);
     const int dt = precision == Q3C_PRECISION_BF16 ? Q3_BF16 : Q3_F32;
     tmp.staged["w.weight"] = HostTensor{{cout, cin, k}, std::vector<float>(w, w + (size_t)cout * cin * k)};
     if (bias) tmp.staged["w.bias"] = HostTensor{{cout}, std::vector<float>(bias, bias + cout)};
@@ -1467,6 +1508,7 @@ int q3c_causal_tconv1d(const float* x, int32_t B, int32_t L, int32_t cin, int32_
                        const float* bias, float* y, int32_t precision, void* stream) {
     if (!x || !w || !y || B < 1 || L < 1 || cin < 8 || cin % 8 || cout < 1 || stride < 1 || k < 1) return Q3C_ERR_INVALID_ARGUMENT;
     q3c_ctx tmp;
+    operator_defaults(&tmp);
     const int dt = precision == Q3C_PRECISION_BF16 ? Q3_BF16 : Q3_F32;
     GemmW g;
     int rc = pack_tconv_host(&tmp, w, bias, cin, cout, k, stride, dt, &g);
@@ -1483,6 +1525,7 @@ int q3c_snake_beta(const float* x, int64_t rows, int32_t C, const float* alpha, 
     if (!x || !y || !alpha || !beta || rows < 0 || C < 1) return Q3C_ERR_INVALID_ARGUMENT;
     if (precision != Q3C_PRECISION_F32 && precision != Q3C_PRECISION_BF16) return Q3C_ERR_INVALID_ARGUMENT;
     q3c_ctx tmp;
+    operator_defaults(&tmp);
     q3c_ctx* c = &tmp;
     hipStream_t s = (hipStream_t)stream;
     tmp.dtype = precision == Q3C_PRECISION_BF16 ? Q3_BF16 : Q3_F32;       // bf16: hardware sine, frequency in revolutions
@@ -1516,6 +1559,7 @@ int q3c_residual_unit(const float* x, int32_t B, int32_t L, int32_t C, int32_t d
     if (!x || !y || !alpha1 || !beta1 || !w1 || !b1 || !alpha2 || !beta2 || !w2 || !b2 || B < 1 || L < 1 || C < 8 || C % 8 || dilation < 1)
         return Q3C_ERR_INVALID_ARGUMENT;
     q3c_ctx tmp;
+    operator_defaults(&tmp);
     q3c_ctx* c = &tmp;
     hipStream_t s = (hipStream_t)stream;
     const int dt = precision == Q3C_PRECISION_BF16 ? Q3_BF16 : Q3_F32;
@@ -1536,7 +1580,7 @@ int q3c_residual_unit(const float* x, int32_t B, int32_t L, int32_t C, int32_t d
         void *raw = nullptr, *sn = nullptr, *h = nullptr, *out = nullptr;
         TRY(dev_alloc(c, n * es, &raw)); TRY(dev_alloc(c, n * es, &sn)); TRY(dev_alloc(c, n * es, &h)); TRY(dev_alloc(c, n * es, &out));
         LAUNCH(c, q3_launch_cast_from_f32(x, raw, (long long)n, dt, s));
-        if (q3_convgemm_fusable(C, dt)) {       // the fused launch reads the raw input and applies the first SnakeBeta itself
+        if (q3_convgemm_fusable(C, dt, c->tuning)) {       // the fused launch reads the raw input and applies the first SnakeBeta itself
             GemmOpts g; g.act = Q3_ACT_SNAKE; g.epi = &a2; g.second = &c2; g.pre = &a1; g.R = raw;
             TRY(gemm(c, c1, raw, B, L, out, L, dt, g, s));
         } else {
@@ -1563,6 +1607,7 @@ int q3c_convnext_block(const float* x, int32_t B, int32_t L, int32_t C, const fl
     if (!x || !y || !dw_w || !dw_b || !ln_w || !ln_b || !pw1_w || !pw1_b || !pw2_w || !pw2_b || !gamma || B < 1 || L < 1 || C < 8 || C % 8)
         return Q3C_ERR_INVALID_ARGUMENT;
     q3c_ctx tmp;
+    operator_defaults(&tmp);
     q3c_ctx* c = &tmp;
     hipStream_t s = (hipStream_t)stream;
     const int dt = precision == Q3C_PRECISION_BF16 ? Q3_BF16 : Q3_F32;

@@ -170,7 +170,7 @@ int encode_sequence(q3c_ctx* c, int B, int L0, bool run, const float* audio, int
             TRY(gemm(c, y.qkv, nrm, B, T, at(o_qkv), T, dt, GemmOpts{}, s));
             LAUNCH_B(c, s, "swa_attention", 4.0 * rows * H * es,
                      q3_launch_swa_attention(at(o_qkv), at(o_att), e.cos_t, e.sin_t, B, T, k.num_attention_heads, k.num_attention_heads, k.head_dim,
-                                             k.sliding_window, dt, s, 0, nullptr, k.max_positions));
+                                             k.sliding_window, dt, s, 0, nullptr, k.max_positions, nullptr, c->tuning));
             GemmOpts o1; o1.scale = y.ls_attn; o1.R = x;
             TRY(gemm(c, y.o, at(o_att), B, T, x, T, dt, o1, s));
             LAUNCH_B(c, s, "layernorm", 2.0 * rows * H * es, q3_launch_layernorm(x, y.ln2_w, y.ln2_b, nrm, rows, H, k.norm_eps, dt, s));
@@ -184,7 +184,7 @@ int encode_sequence(q3c_ctx* c, int B, int L0, bool run, const float* audio, int
         float* emb = emb_out ? emb_out : (float*)at(o_emb);
         TRY(gemm(c, e.ds, at(o_pad), B, Tg + 1, emb, Tg, Q3_F32, GemmOpts{}, s));
         LAUNCH(c, q3_launch_rvq_encode(emb, B, Tg, c->rvq_in_dim, c->cfg.num_quantizers, c->cfg.codebook_size, c->cfg.codebook_dim, c->tables_dev,
-                                       (const void* const*)c->tables_t_dev, c->group_start_dev, c->G, c->rvq_in_proj, (long long*)codes, s));
+                                       (const void* const*)c->tables_t_dev, c->group_start_dev, c->G, c->rvq_in_proj, (long long*)codes, s, c->tuning));
     }
     if (ws_total) *ws_total = off;
     return 0;

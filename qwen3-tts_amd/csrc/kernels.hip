@@ -4,7 +4,6 @@
 #include "common.h"
 #include <algorithm>
 
-extern int q3_convgemm_tuning;      // measurement switches (convgemm.hip); bit 256 here: the vector-ALU attention for every case
 
 namespace {
 
@@ -1182,11 +1181,11 @@ hipError_t q3_launch_rvq_gather_sum(const long long* codes, int B, int Q, int T,
 
 hipError_t q3_launch_rvq_encode(const float* emb, int B, int T, int in_dim, int Q, int bins, int D, const float* const* tables_dev,
                                 const void* const* tables_t_dev, const int* group_start_dev, int G, const float* in_proj_dev,
-                                long long* codes, hipStream_t s) {
+                                long long* codes, hipStream_t s, int tuning) {
     const long long frames = (long long)B * T;
     if (frames == 0) return hipSuccess;
     if ((D & 3) || D < 4 || in_dim < 1 || (!in_proj_dev && in_dim != D)) return hipErrorInvalidValue;
-    if (D == 256 && bins % 128 == 0 && !(q3_convgemm_tuning & (1 << 20))) {       // full-size code books: the search on the fp32 matrix op
+    if (D == 256 && bins % 128 == 0 && !(tuning & (1 << 20))) {       // full-size code books: the search on the fp32 matrix op
         const size_t ldsm = ((size_t)RVQM_FT * (in_dim + 4 + D + 1) + 4 * RVQM_FT) * sizeof(float) + (4 * RVQM_FT + RVQM_FT) * sizeof(int);
         if (ldsm <= 160 * 1024 && in_dim % 8 == 0) {
             auto km = rvq_encode_mfma_kernel<256>;
@@ -1254,7 +1253,7 @@ hipError_t q3_launch_dwconv_ln(const void* x, const float* w, const float* b, co
 
 hipError_t q3_launch_swa_attention(const void* qkv, void* out, const float* cos_t, const float* sin_t, int B, int T, int nh,
                                    int nkv, int d, int window, int dtype, hipStream_t s, int hist, const int* pos0, int max_pos,
-                                   const Q3KvRing* ring_in) {
+                                   const Q3KvRing* ring_in, int tuning) {
     if (B == 0 || T == 0) return hipSuccess;
     if (hist < 0 || max_pos < 1) return hipErrorInvalidValue;
     if (hist > 0 && (!ring_in || !ring_in->state || !ring_in->slots || !pos0)) return hipErrorInvalidValue;
@@ -1277,7 +1276,7 @@ hipError_t q3_launch_swa_attention(const void* qkv, void* out, const float* cos_
             return d == 64 ? step(swa_attention_step_kernel<bf16, 64>, (const bf16*)qkv, (bf16*)out) : step(swa_attention_step_kernel<bf16, 0>, (const bf16*)qkv, (bf16*)out);
         return d == 64 ? step(swa_attention_step_kernel<float, 64>, (const float*)qkv, (float*)out) : step(swa_attention_step_kernel<float, 0>, (const float*)qkv, (float*)out);
     }
-    if (dtype == Q3_BF16 && d == AM_D && hist == 0 && !pos0 && window >= 1 && window <= 257 && nkv > 0 && nh % nkv == 0 && !(q3_convgemm_tuning & 256)) {
+    if (dtype == Q3_BF16 && d == AM_D && hist == 0 && !pos0 && window >= 1 && window <= 257 && nkv > 0 && nh % nkv == 0 && !(tuning & 256)) {
         const bool wide = window > 97;             // nine key tiles per wave instead of four
         const size_t ldsm = (size_t)2 * (AM_QB + 32 * (wide ? 8 : 3)) * 128;
         auto km = wide ? swa_attention_mfma_kernel<9> : swa_attention_mfma_kernel<4>;

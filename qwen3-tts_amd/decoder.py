@@ -9,6 +9,7 @@ libq3c.so (hand-written gfx950 kernels); torch is used for device memory and str
 from __future__ import annotations
 
 import ctypes as C
+import os
 import threading
 from typing import Dict, List, Optional, Sequence, Tuple, Union
 
@@ -139,6 +140,8 @@ class Decoder:
                 shape = (C.c_int64 * t.dim())(*t.shape)
                 self._check(self._lib.q3c_load_weight(self._ctx, name.encode(), C.c_void_p(t.data_ptr()), shape, t.dim()))
             self._check(self._lib.q3c_finalize(self._ctx))
+        if os.environ.get("Q3C_TUNING"):       # measurement aid: this context's A/B switches (q3c_debug_set_tuning)
+            self.set_tuning(int(os.environ["Q3C_TUNING"]))
 
     @classmethod
     def from_local(cls, path: str, device: Union[str, torch.device] = "cuda:0", precision: str = "bf16",
@@ -514,6 +517,10 @@ class Decoder:
         self._check(self._lib.q3c_profile_read(self._ctx, arr, cap, C.byref(n)))
         return [dict(kernel=arr[i].kernel.decode(), launches=int(arr[i].launches), ms=float(arr[i].ms),
                      flops=float(arr[i].flops), bytes=float(arr[i].bytes)) for i in range(n.value)]
+
+    def set_tuning(self, bits: int) -> None:
+        """Measurement switches of THIS decoder's context (include/q3c.h, q3c_debug_set_tuning); 0 = defaults."""
+        self._check(self._lib.q3c_debug_set_tuning(self._ctx, int(bits)))
 
     def set_tap(self, stage: int, elements: int) -> torch.Tensor:
         """Debug/parity aid: capture a stage's output of the following forwards as fp32 (see include/q3c.h)."""

@@ -162,3 +162,34 @@ def test_flagship_fp32_one_frame_stream_equals_the_bulk_forward(cond):
     assert e <= 2e-5, e                                                        # measured 4.3e-6
     pool.close()
     dec.close()
+
+
+def test_decoder_from_a_local_safetensors_checkpoint_matches_the_oracle(tmp_path):
+    """Weights written to <model dir>/speech_tokenizer/{config.json, model.safetensors} (fp32, key prefix "decoder."), loaded
+    with Decoder.from_local - never from a live state dict - and decoded: fp32 at the 1e-3 / 60 dB bar against the oracle on the
+    same tensors; a bf16-stored checkpoint within the bf16 tolerance; warm-up runs; hub names are refused."""
+    from qwen3_tts_amd import checkpoint
+    cfg = q3.tiny_config("split_rvq", sliding_window=40)
+    w = q3.synthetic_weights(cfg, seed=5, profile="conditioned")
+    root = tmp_path / "Qwen3-TTS-12Hz-0.6B-Base"
+    checkpoint.save_local(str(root / "speech_tokenizer"), cfg, w)
+    dec = Decoder.from_local(str(root), device="cuda:0", precision="f32")
+    assert dec.cfg == cfg
+    assert dec.warmup(batch=2, frames=7) > 0.0
+    codes = q3.random_codes(cfg, 2, 61, seed=8)
+    ref = oracle.forward(cfg, w, codes)
+    got = dec.forward(codes)
+    print(f"from_local fp32: max|err| {max_abs(ref, got):.3e}, {snr_db(ref, got):.1f} dB")
+    assert max_abs(ref, got) <= F32_MAX_ABS and snr_db(ref, got) >= F32_SNR_DB
+    wavs, sr = dec.decode([codes[0].t(), {"audio_codes": codes[1, :, :30]}])
+    assert sr == 24000 and np.array_equal(wavs[0], got[0, 0].cpu().numpy()) and wavs[1].shape == (cfg.output_length(30),)
+    dec.close()
+    checkpoint.save_local(str(tmp_path / "bf16" / "tok"), cfg, w, dtype=torch.bfloat16)
+    dec16 = Decoder.from_local(str(tmp_path / "bf16"), device="cuda:0", precision="bf16")
+    w16 = {k: v.to(torch.bfloat16).float() for k, v in w.items()}          # what the file holds
+    got16 = dec16.forward(codes)
+    s = snr_db(oracle.forward(cfg, w16, codes), got16)
+    print(f"from_local bf16 checkpoint, bf16 decode: {s:.1f} dB")
+    assert s >= BF16_WAV_SNR_DB - 1.0
+    with pytest.raises(FileNotFoundError, match="hub names"):
+        Decoder.from_local("Qwen/Qwen3-TTS-12Hz-0.6B-Base")

@@ -80,10 +80,10 @@ def test_flagship_transformer_bf16_both_attention_kernels_vs_oracle(flagship, fl
     got = {}
     try:
         for name, bits in (("matrix cores", 0), ("vector ALU", 256)):
-            lib.q3c_debug_set_tuning(bits)
+            flagship_bf16.set_tuning(bits)
             got[name] = flagship_bf16.transformer(x).cpu().numpy()
     finally:
-        lib.q3c_debug_set_tuning(0)
+        flagship_bf16.set_tuning(0)
     for name, y in got.items():
         assert np.isfinite(y).all(), name
         assert snr_db(want, y) >= BF16_TRANSFORMER_SNR_DB, (name, T, snr_db(want, y))
@@ -105,10 +105,10 @@ def test_matrix_core_attention_grouped_heads_and_windows_vs_oracle(window, kv_he
     got = {}
     try:
         for name, bits in (("matrix cores", 0), ("vector ALU", 256)):
-            lib.q3c_debug_set_tuning(bits)
+            dec.set_tuning(bits)
             got[name] = dec.transformer(x).cpu().numpy()
     finally:
-        lib.q3c_debug_set_tuning(0)
+        dec.set_tuning(0)
     print(f"window {window}, {kv_heads} kv heads: " + ", ".join(f"{k} {snr_db(want, v):.1f} dB" for k, v in got.items()))
     for name, y in got.items():
         assert np.isfinite(y).all() and snr_db(want, y) >= 38.0, (name, snr_db(want, y))
@@ -122,10 +122,10 @@ def test_final_conv_fold_at_32_channels():
     codes = q3.random_codes(cfg, 2, 40, seed=6).cuda()
     lib = _lib.load()
     try:
-        lib.q3c_debug_set_tuning(512)
+        dec.set_tuning(512)
         want = dec.forward(codes).cpu().numpy()
     finally:
-        lib.q3c_debug_set_tuning(0)
+        dec.set_tuning(0)
     got = dec.forward(codes).cpu().numpy()
     assert np.isfinite(got).all() and max_abs(want, got) <= 2e-6, max_abs(want, got)
     dec.profile(True, detail=True)
@@ -145,10 +145,10 @@ def test_final_conv_folded_into_the_last_unit_equals_its_own_launch(flagship, fl
     for B, T in ((2, 125), (1, 3)):
         codes = q3.random_codes(cfg, B, T, seed=40 + T).cuda()
         try:
-            lib.q3c_debug_set_tuning(512)
+            flagship_bf16.set_tuning(512)
             want = flagship_bf16.forward(codes).cpu().numpy()
         finally:
-            lib.q3c_debug_set_tuning(0)
+            flagship_bf16.set_tuning(0)
         got = flagship_bf16.forward(codes).cpu().numpy()
         assert got.shape == want.shape == (B, 1, cfg.output_length(T))
         assert np.isfinite(got).all() and max_abs(want, got) <= 2e-6, max_abs(want, got)

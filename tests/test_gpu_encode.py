@@ -71,10 +71,10 @@ def test_encode_at_mimi_sizes_vs_oracle():
     from qwen3_tts_amd import _lib
     lib = _lib.load()
     try:
-        lib.q3c_debug_set_tuning(256)
+        dec16.set_tuning(256)
         _, emb_v = dec16.encode(audio, return_embeddings=True)
     finally:
-        lib.q3c_debug_set_tuning(0)
+        dec16.set_tuning(0)
     snr_v = snr_db(want_emb, emb_v.cpu().numpy())
     print(f"mimi-size encoder bf16, vector-ALU attention: embeddings {snr_v:.1f} dB; between the two kernels {snr_db(emb_v.cpu().numpy(), emb16.cpu().numpy()):.1f} dB")
     assert snr_v >= 30.0 and abs(snr_v - snr) <= 3.0
@@ -94,10 +94,10 @@ def test_rvq_search_kernels_agree():
     lib = _lib.load()
     a = dec.encode(audio).cpu()
     try:
-        lib.q3c_debug_set_tuning(1 << 20)
+        dec.set_tuning(1 << 20)
         b = dec.encode(audio).cpu()
     finally:
-        lib.q3c_debug_set_tuning(0)
+        dec.set_tuning(0)
     assert a.shape == b.shape == (3, cfg.num_quantizers, ecfg.frames(98765))
     first = float((a[:, 0] == b[:, 0]).float().mean())
     frames_equal = float((a == b).all(dim=1).float().mean())

@@ -476,11 +476,11 @@ def test_one_launch_unit_at_384_channels_matches_two_launches():
     want = oracle.residual_unit(x, w, "ru.", d).permute(0, 2, 1).numpy()
     two = D.residual_unit(xd, w, "ru.", d, precision="bf16").cpu().numpy()
     lib = _lib.load()
-    lib.q3c_debug_set_tuning(64)
+    lib.q3c_debug_set_operator_context(64, None, 0)
     try:
         one = D.residual_unit(xd, w, "ru.", d, precision="bf16").cpu().numpy()
     finally:
-        lib.q3c_debug_set_tuning(0)
+        lib.q3c_debug_set_operator_context(0, None, 0)
     top = float(np.abs(want).max())
     for tag, got in (("two launches", two), ("one launch", one)):
         assert max_abs(want, got) <= BF16_CHAIN_REL * max(top, 1.0), (tag, max_abs(want, got), top)

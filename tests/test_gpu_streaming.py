@@ -187,11 +187,11 @@ def test_flagship_bf16_streams_track_the_bulk_forward():
     T = 30
     codes = q3.random_codes(cfg, 2, T, seed=9)
     lib = _lib.load()
-    lib.q3c_debug_set_tuning(256)
+    dec.set_tuning(256)
     try:
         ref = dec.forward(codes)[:, 0].float()
     finally:
-        lib.q3c_debug_set_tuning(0)
+        dec.set_tuning(0)
     pool = dec.open_streams(4)
     ids = pool.open_many(2)
     outs, t = [], 0

@@ -306,6 +306,132 @@ def test_install_hook_refuses_mismatches():
         install.install_decoder(cpu_model, decoder_factory=_FakeDecoder)
 
 
+# ---- model manager and local checkpoints (reference models.py:15-132, config.py:12-16,23-72) ---------------------------
+def test_local_checkpoint_round_trip_and_refusals(tmp_path):
+    """save_local / load_local: config.json + model.safetensors in a sub-directory of a model directory, a key prefix, a
+    rename map, an upstream-style config that cannot be trusted for shape-determined sizes; hub names and missing paths are
+    refused before anything is read."""
+    from qwen3_tts_amd import checkpoint
+    cfg = q3.tiny_config("split_rvq", sliding_window=40, rope_theta=5000.0)
+    w = q3.synthetic_weights(cfg, seed=6)
+    extra = dict(w)
+    extra["encoder.unrelated"] = torch.zeros(4)
+    root = tmp_path / "Qwen3-TTS-12Hz-0.6B-Base"
+    checkpoint.save_local(str(root / "speech_tokenizer"), cfg, extra, prefix="decoder.")
+    got_cfg, got_w = checkpoint.load_local(str(root))
+    assert got_cfg == cfg                                          # sliding_window / rope_theta come from config.json, sizes from shapes
+    assert set(got_w) == set(w) and all(torch.equal(got_w[k], w[k]) for k in w)
+    one_file = checkpoint.load_local(str(root / "speech_tokenizer" / "model.safetensors"))
+    assert one_file[0] == cfg
+    # key names of another convention: refused until a rename map says how they translate
+    other = tmp_path / "renamed"
+    checkpoint.save_local(str(other), cfg, {k.replace("quantizer.", "rvq."): v for k, v in w.items()}, prefix="tok.decoder.")
+    with pytest.raises(KeyError, match="rename"):
+        checkpoint.load_local(str(other))
+    assert checkpoint.load_local(str(other), rename={"rvq.": "quantizer."})[0] == cfg
+    # a tensor of the wrong shape
+    bad = dict(w)
+    bad["decoder.1.block.2.conv1.conv.weight"] = torch.zeros(3, 3, 7)
+    checkpoint.save_local(str(tmp_path / "bad"), cfg, bad)
+    with pytest.raises(ValueError, match="missing or mis-shaped"):
+        checkpoint.load_local(str(tmp_path / "bad"))
+    for name in ("Qwen/Qwen3-TTS-12Hz-0.6B-Base", str(tmp_path / "absent")):
+        with pytest.raises(FileNotFoundError, match="local director"):
+            checkpoint.load_local(name)
+    (tmp_path / "empty").mkdir()
+    with pytest.raises(FileNotFoundError, match="safetensors"):
+        checkpoint.load_local(str(tmp_path / "empty"))
+    # bf16 storage, as a released checkpoint has it: values come back as the bf16-rounded fp32
+    checkpoint.save_local(str(tmp_path / "bf16"), cfg, w, dtype=torch.bfloat16)
+    _, w16 = checkpoint.load_local(str(tmp_path / "bf16"))
+    k = "decoder.0.conv.weight"
+    assert w16[k].dtype == torch.float32 and torch.equal(w16[k], w[k].to(torch.bfloat16).float())
+
+
+def test_model_manager_follows_the_reference_and_loads_local_paths_only(tmp_path):
+    """Cache by model type, dtype map, attention string, TTS_* flags, aliases, default model, warm-up - with a stub for
+    Qwen3TTSModel.from_pretrained - and the one deliberate difference: a model path that is not a local directory raises
+    instead of being handed to the factory as a hub name."""
+    from qwen3_tts_amd import models
+    cfg = q3.tiny_config("split_rvq")
+    w = q3.synthetic_weights(cfg, seed=0)
+    calls = []
+
+    class Model(_StubTTS):
+        def __init__(self):
+            super().__init__(_StubTokenizer(_StubDecoderModule(cfg, w)))
+            self.generated = []
+
+        def generate_voice_clone(self, **kw):
+            self.generated.append(("voice_clone", kw))
+
+        def generate_custom_voice(self, **kw):
+            self.generated.append(("custom_voice", kw))
+
+    def factory(path, device_map, dtype, attn_implementation):
+        calls.append((path, device_map, dtype, attn_implementation))
+        return Model()
+
+    class Warm(_FakeDecoder):
+        warmed = 0
+
+        def warmup(self, batch, frames):
+            Warm.warmed += 1
+
+    def installer(model, precision, device, **kw):
+        from qwen3_tts_amd import install
+        return install.install_decoder(model, precision=precision, device=device, decoder_factory=Warm, **kw)
+
+    base = tmp_path / "models" / "Qwen3-TTS-12Hz-0.6B-Base"
+    base.mkdir(parents=True)
+    custom = tmp_path / "elsewhere"
+    custom.mkdir()
+    sample = tmp_path / "sample.mp3"
+    sample.write_bytes(b"x")
+    env = {"TTS_DEVICE": "cuda:3", "TTS_DTYPE": "float32", "TTS_USE_FLASH_ATTENTION": "true", "TTS_USE_WARMUP": "true",
+           "MODEL_1_7B_CUSTOM_VOICE": str(custom), "TTS_WARMUP_AUDIO": str(sample)}
+    mm = models.TTSModelManager(factory=factory, installer=installer, env=env, models_root=str(tmp_path / "models"),
+                                decoder_kwargs={"max_positions": 77})
+    assert (mm.device, mm.dtype, mm.attn_impl, mm.default_model) == ("cuda:3", torch.float32, "flash_attention_2", "base_0.6b")
+    assert not mm.is_loaded("base_0.6b") and mm.get_loaded_models() == []
+    mm.load_default_models()                                       # TTS_DEFAULT_MODEL unset: base_0.6b (config.py:72)
+    assert calls == [(str(base), "cuda:3", torch.float32, "flash_attention_2")]
+    m = mm.get_model("base_0.6b")
+    assert mm.load_model("base_0.6b") is m and len(calls) == 1     # cached: the factory is not called again
+    dec = mm.get_decoder("base_0.6b")
+    assert (dec.precision, dec.device, dec.kw) == ("f32", "cuda:3", {"max_positions": 77}) and dec.cfg == cfg
+    assert m.model.speech_tokenizer.decode([0]) == ("mi355x", 24000)        # the decode was swapped in
+    assert Warm.warmed == 1 and m.generated[0][0] == "voice_clone" and m.generated[0][1]["ref_audio"] == str(sample)
+    assert m.generated[0][1]["x_vector_only_mode"] is True and m.generated[0][1]["max_new_tokens"] == 256
+    # an environment override, reached through the alias too; custom-voice models warm up with a speaker
+    m2 = mm.get_model("custom_voice")
+    assert calls[-1][0] == str(custom) and m2.generated[0] == ("custom_voice", dict(text=models.WARMUP_TEXT, language="Korean",
+                                                                                     speaker="Sohee", max_new_tokens=256))
+    assert mm.get_loaded_models() == ["base_0.6b", "custom_voice"]
+    # unknown type: the reference's message; a directory that does not exist: refused, the factory never sees a hub name
+    with pytest.raises(ValueError, match="Unknown model type: nope"):
+        mm.load_model("nope")
+    n = len(calls)
+    with pytest.raises(FileNotFoundError, match="never resolves hub names"):
+        mm.load_model("base_1.7b")
+    hub = models.TTSModelManager(factory=factory, installer=installer, env={"MODEL_0_6B_BASE": "Qwen/Qwen3-TTS-12Hz-0.6B-Base"},
+                                 models_root=str(tmp_path / "models"))
+    with pytest.raises(FileNotFoundError, match="never resolves hub names"):
+        hub.load_default_models()
+    assert len(calls) == n
+    # defaults of the reference: bfloat16 -> the bf16 decode, sdpa, no warm-up; an unknown dtype name falls back to bfloat16
+    d = models.TTSModelManager(factory=factory, installer=installer, env={"TTS_DTYPE": "float8"}, models_root=str(tmp_path / "models"))
+    assert (d.device, d.dtype, d.attn_impl, d.use_warmup) == ("cuda:0", torch.bfloat16, "sdpa", False)
+    d.load_model("base_0.6b")
+    assert d.get_decoder("base_0.6b").precision == "bf16" and Warm.warmed == 2       # no warm-up without TTS_USE_WARMUP
+    # float16 models decode in fp32 (no fp16 kernel path; never fewer mantissa bits than the model asked for)
+    h = models.TTSModelManager(factory=factory, installer=installer, env={"TTS_DTYPE": "float16"}, models_root=str(tmp_path / "models"))
+    assert h.get_decoder("base_0.6b").precision == "f32"
+    # without the qwen-tts package and without an injected factory the load says what is missing
+    with pytest.raises(ImportError, match="qwen-tts"):
+        models.TTSModelManager(env={}, models_root=str(tmp_path / "models")).load_model("base_0.6b")
+
+
 # ---- torch custom ops: registration and shape functions (no GPU: the kernels themselves are CUDA-only) -------------
 def test_torch_ops_are_registered_with_shape_functions():
     from torch._subclasses.fake_tensor import FakeTensorMode

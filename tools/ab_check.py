@@ -14,10 +14,10 @@ cfg = q3.tiny_config("split_rvq", decoder_dim=1536, latent_dim=256, hidden_size=
 dec = Decoder(cfg, q3.synthetic_weights(cfg, 0), precision="bf16")
 codes = q3.random_codes(cfg, 3, 40, seed=3).cuda()
 lib = _lib.load()
-lib.q3c_debug_set_tuning(0)
+dec.set_tuning(0)
 a = dec.forward(codes)
-lib.q3c_debug_set_tuning(bits)
+dec.set_tuning(bits)
 b = dec.forward(codes)
-lib.q3c_debug_set_tuning(0)
+dec.set_tuning(0)
 torch.cuda.synchronize()
 print("max |diff|", float((a - b).abs().max()), "max |a|", float(a.abs().max()))

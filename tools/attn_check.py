@@ -20,11 +20,11 @@ lib = _lib.load()
 for T in (1, 31, 100, 129, 300):
     x = torch.randn(2, T, cfg.latent_dim, generator=torch.Generator().manual_seed(T))
     want = oracle.transformer(cfg, x, w)
-    lib.q3c_debug_set_tuning(0)
+    dec.set_tuning(0)
     a = dec.transformer(x).float().cpu()
-    lib.q3c_debug_set_tuning(256)
+    dec.set_tuning(256)
     b = dec.transformer(x).float().cpu()
-    lib.q3c_debug_set_tuning(0)
+    dec.set_tuning(0)
     snr = lambda ref, y: float(10 * torch.log10((ref ** 2).sum() / ((ref - y) ** 2).sum()))
     print(f"T={T}: matrix-core kernel vs oracle {snr(want, a):.1f} dB, vector kernel vs oracle {snr(want, b):.1f} dB, "
           f"each other {snr(b, a):.1f} dB; max|y| {float(want.abs().max()):.2f}; finite {bool(torch.isfinite(a).all())}")

@@ -23,7 +23,7 @@ lib = _lib.load()
 dec.forward(codes)
 torch.cuda.synchronize()
 for tuning in args.tuning:
-    lib.q3c_debug_set_tuning(int(tuning))
+    dec.set_tuning(int(tuning))
     dec.forward(codes)
     torch.cuda.synchronize()
     dec.profile(True, detail=True)
@@ -37,4 +37,4 @@ for tuning in args.tuning:
     for p in rows[: (40 if len(args.tuning) == 1 else 12)]:
         rate = f"{p['flops'] / p['ms'] / 1e9:8.1f} TF" if p["flops"] else f"{p['bytes'] / p['ms'] / 1e6:8.1f} GB/s"
         print(f"{p['ms'] / 2:9.3f} ms {100 * p['ms'] / tot:5.1f}%  x{p['launches'] // 2:<3d} {rate}  {p['kernel']}")
-lib.q3c_debug_set_tuning(0)
+dec.set_tuning(0)

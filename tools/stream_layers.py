@@ -17,7 +17,7 @@ args = ap.parse_args()
 cfg = q3.flagship_config()
 dec = Decoder(cfg, q3.synthetic_weights(cfg, 0), precision="bf16")
 from qwen3_tts_amd import _lib
-_lib.load().q3c_debug_set_tuning(args.tuning)
+dec.set_tuning(args.tuning)
 pool = dec.open_streams(args.streams)
 ids = torch.tensor(pool.open_many(args.streams), dtype=torch.int32, device="cuda")
 codes = q3.random_codes(cfg, args.streams, args.frames, 1).cuda()

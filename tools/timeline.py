@@ -12,9 +12,8 @@ from qwen3_tts_amd import _lib
 from qwen3_tts_amd import decoder as D
 
 lib = _lib.load()
-lib.q3c_debug_set_timeline.argtypes = [C.c_void_p, C.c_int]
-lib.q3c_debug_set_timeline.restype = None
 SLOTS = 4096
+TUNING = int(os.environ.get("Q3C_TUNING", "0"))
 buf = torch.zeros((SLOTS, 8), dtype=torch.int64, device="cuda")
 g = torch.Generator().manual_seed(0)
 
@@ -44,9 +43,9 @@ def unit(Cn, dil, B, L):
          "ru.conv2.conv.weight": torch.randn(Cn, Cn, 1, generator=g) * Cn ** -0.5, "ru.conv2.conv.bias": torch.zeros(Cn)}
     x = torch.randn(B, L, Cn, device="cuda")
     D.residual_unit(x, w, "ru.", dil, precision="bf16")          # warm-up (allocations, code load)
-    lib.q3c_debug_set_timeline(C.c_void_p(buf.data_ptr()), SLOTS)
+    lib.q3c_debug_set_operator_context(TUNING, C.c_void_p(buf.data_ptr()), SLOTS)
     D.residual_unit(x, w, "ru.", dil, precision="bf16")
-    lib.q3c_debug_set_timeline(None, 0)
+    lib.q3c_debug_set_operator_context(TUNING, None, 0)
     report(f"residual unit, {Cn} channels, dilation {dil}, {B} x {L} rows", True)
 
 
@@ -54,9 +53,9 @@ def conv(cin, cout, k, dil, B, L):
     w = torch.randn(cout, cin, k, generator=g) * (k * cin) ** -0.5
     x = torch.randn(B, L, cin, device="cuda")
     D.causal_conv1d(x, w, torch.zeros(cout), dil, "bf16")
-    lib.q3c_debug_set_timeline(C.c_void_p(buf.data_ptr()), SLOTS)
+    lib.q3c_debug_set_operator_context(TUNING, C.c_void_p(buf.data_ptr()), SLOTS)
     D.causal_conv1d(x, w, torch.zeros(cout), dil, "bf16")
-    lib.q3c_debug_set_timeline(None, 0)
+    lib.q3c_debug_set_operator_context(TUNING, None, 0)
     report(f"conv k{k} d{dil} {cin}->{cout}, {B} x {L} rows", False)
 
 
@@ -64,9 +63,9 @@ def tconv(cin, cout, stride, B, L):
     w = torch.randn(cin, cout, 2 * stride, generator=g) * (2 * cin) ** -0.5
     x = torch.randn(B, L, cin, device="cuda")
     D.causal_trans_conv1d(x, w, torch.zeros(cout), stride, "bf16")
-    lib.q3c_debug_set_timeline(C.c_void_p(buf.data_ptr()), SLOTS)
+    lib.q3c_debug_set_operator_context(TUNING, C.c_void_p(buf.data_ptr()), SLOTS)
     D.causal_trans_conv1d(x, w, torch.zeros(cout), stride, "bf16")
-    lib.q3c_debug_set_timeline(None, 0)
+    lib.q3c_debug_set_operator_context(TUNING, None, 0)
     report(f"transposed conv k{2 * stride} s{stride} {cin}->{cout} (single output), {B} x {L} rows", False)
 
 
