@@ -106,6 +106,15 @@ int q3c_forward(q3c_ctx* ctx, const int64_t* codes_dev, int32_t batch, int32_t f
 int q3c_forward_skip(q3c_ctx* ctx, const int64_t* codes_dev, int32_t batch, int32_t frames, int32_t skip_frames, float* wav_dev,
                      void* workspace_dev, size_t workspace_bytes, void* hip_stream);
 
+/* q3c_forward_skip whose kept samples go straight to their places in a larger output (the wrapper's `wavs[i]` of reference
+ * server.py:379-389 are slices of one tensor; chunked_decode's torch.cat, sib :3695-3696, becomes a placement): spans_dev is a
+ * DEVICE array [batch][2] of int64 (destination offset into out_dev in samples, count); item b's samples skip_frames *
+ * total_upsample .. + count - 1 of its forward are written to out_dev + offset and nothing else is written, so count <=
+ * frames * total_upsample - trim - skip_frames * total_upsample, and a count of 0 drops the item (a padding row).  Same
+ * arithmetic, hence the same bits, as q3c_forward_skip. */
+int q3c_forward_scatter(q3c_ctx* ctx, const int64_t* codes_dev, int32_t batch, int32_t frames, int32_t skip_frames, const int64_t* spans_dev,
+                        float* out_dev, void* workspace_dev, size_t workspace_bytes, void* hip_stream);
+
 /* q3c_forward for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses
  * that forbid hipMalloc).  It has no counterpart in the reference.  Same result as q3c_forward, bit for bit, but the workspace is
  * a static device array of Q3C_STATIC_SCRATCH_BYTES inside the library (each GPU the library runs on holds its own copy

@@ -19,7 +19,7 @@ STATIC_SCRATCH_BYTES = 64 << 20        # Q3C_STATIC_SCRATCH_BYTES of include/q3c
 STAGE_RVQ_OUT, STAGE_TRANSFORMER_IN, STAGE_TRANSFORMER_OUT, STAGE_UPSAMPLE0, STAGE_CONV_IN, STAGE_BLOCK0 = 0, 1, 2, 3, 16, 17
 
 EXPORTS = ["q3c_create", "q3c_destroy", "q3c_last_error", "q3c_version", "q3c_load_weight", "q3c_finalize",
-           "q3c_workspace_bytes", "q3c_output_length", "q3c_forward", "q3c_forward_skip", "q3c_forward_static", "q3c_rvq_dequant_f32", "q3c_rvq_encode", "q3c_check_errors",
+           "q3c_workspace_bytes", "q3c_output_length", "q3c_forward", "q3c_forward_skip", "q3c_forward_scatter", "q3c_forward_static", "q3c_rvq_dequant_f32", "q3c_rvq_encode", "q3c_check_errors",
            "q3c_set_tap", "q3c_causal_conv1d", "q3c_causal_tconv1d", "q3c_snake_beta", "q3c_profile_enable",
            "q3c_profile_read", "q3c_stream_pool_create", "q3c_stream_pool_destroy", "q3c_stream_state_bytes",
            "q3c_stream_reset", "q3c_stream_workspace_bytes", "q3c_stream_push", "q3c_stream_push_graph", "q3c_residual_unit", "q3c_convnext_block",
@@ -111,6 +111,7 @@ def load() -> C.CDLL:
     lib.q3c_output_length.argtypes = [vp, i32, i64p]
     lib.q3c_forward.argtypes = [vp, vp, i32, i32, vp, vp, C.c_size_t, vp]
     lib.q3c_forward_skip.argtypes = [vp, vp, i32, i32, i32, vp, vp, C.c_size_t, vp]
+    lib.q3c_forward_scatter.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, C.c_size_t, vp]
     lib.q3c_forward_static.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.q3c_rvq_dequant_f32.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.q3c_rvq_encode.argtypes = [vp, vp, i32, i32, i32, vp, vp]

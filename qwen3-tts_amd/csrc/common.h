@@ -84,7 +84,11 @@ hipError_t q3_launch_mean_embedding(const long long* codes, int B, int Q, int T,
 // y[b, m] = act(bias + sum_t P[b, m - (taps - 1) + t, t]) over the rows m - (taps - 1) + t >= 0: the one-channel causal conv
 // whose per-tap products a fused unit left in P ([B][M][8] fp32); act: Q3_ACT_NONE or Q3_ACT_CLAMP
 // m_first: rows below it are not written (their P rows may not exist; the rows m_first - (taps - 1) .. do)
-hipError_t q3_launch_tap_sum(const float* P, const float* bias, float* y, int B, int M, int taps, int act, hipStream_t s, int m_first = 0);
+// spans (device, [B][2] = destination offset into y in samples, count; or null): item b's samples m_first .. m_first + count - 1 go
+// to y + offset and nothing else is written
+hipError_t q3_launch_tap_sum(const float* P, const float* bias, float* y, int B, int M, int taps, int act, hipStream_t s, int m_first = 0,
+                             const long long* spans = nullptr);
+hipError_t q3_launch_span_copy(const float* src /*[B][M]*/, int B, int M, int m_first, const long long* spans, float* out, hipStream_t s);
 // ---- the encode side's small kernels: first conv (one audio channel -> F, k taps, causal; optionally also its ELU),
 // LayerNorm with bias, replicate padding ----
 // y2 (or null) receives ELU(y), items y2_bstride elements apart

@@ -1082,7 +1082,7 @@ int q3c_rvq_dequant_f32(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, 
 }
 
 static int forward_impl(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, float* wav, void* ws, size_t ws_bytes, void* stream,
-                        int32_t skip_frames = 0);
+                        int32_t skip_frames = 0, const int64_t* spans = nullptr);
 
 int q3c_rvq_encode(q3c_ctx* c, const float* emb, int32_t B, int32_t T, int32_t in_dim, int64_t* codes, void* stream) {
     if (!c) return Q3C_ERR_INVALID_ARGUMENT;
@@ -1132,8 +1132,17 @@ int q3c_forward_static(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, f
     return forward_impl(c, codes, B, T, wav, c->static_scratch, (size_t)Q3C_STATIC_SCRATCH_BYTES, stream);
 }
 
+int q3c_forward_scatter(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, int32_t skip_frames, const int64_t* spans, float* out,
+                        void* ws, size_t ws_bytes, void* stream) {
+    if (!c) return Q3C_ERR_INVALID_ARGUMENT;
+    if (!c->finalized) return fail(c, Q3C_ERR_STATE, "q3c_finalize has not run");
+    if (!codes || !out || !spans || !ws || B < 1 || T < 1) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "q3c_forward_scatter: bad argument");
+    if (skip_frames < 0 || skip_frames >= T) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "q3c_forward_scatter: skip_frames must be in [0, frames)");
+    return forward_impl(c, codes, B, T, out, ws, ws_bytes, stream, skip_frames, spans);
+}
+
 static int forward_impl(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, float* wav, void* ws, size_t ws_bytes, void* stream,
-                        int32_t skip_frames) {
+                        int32_t skip_frames, const int64_t* spans) {
     const q3c_config& k = c->cfg;
     if (T > k.max_positions) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "frames exceed max_positions");
     if ((uintptr_t)ws & 255) return fail(c, Q3C_ERR_INVALID_ARGUMENT, "workspace must be 256-byte aligned");
@@ -1201,6 +1210,7 @@ static int forward_impl(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, 
     std::vector<std::vector<int>> unit_row0(nblk);
     for (size_t i = 0; i < nblk; ++i) unit_row0[i].assign(c->blocks[i].units.size(), 0);
     int out_row0 = 0, conv_in_row0 = 0;
+    const int skip_in = skip_frames;
     for (const auto& t : c->taps) if (t.second.first) skip_frames = 0;       // a captured stage is captured whole
     if (skip_frames > 0) {
         long long per_frame = 1;
@@ -1281,12 +1291,18 @@ static int forward_impl(q3c_ctx* c, const int64_t* codes, int32_t B, int32_t T, 
         cur = sn;
         if (!(folded && i + 1 == c->blocks.size())) TRY(tap_out(c, Q3C_STAGE_BLOCK0 + (int)i, cur, (size_t)B * L * ch, s));
     }
+    // With `spans` (q3c_forward_scatter) item b's kept samples go straight to their place in the caller's output: the folded
+    // path's diagonal sum writes them there; otherwise the final conv writes a free arena and one copy launch places them.
+    const int first_kept = (int)((long long)skip_in * c->total_upsample);
     if (folded) {   // the final conv's taps summed along the diagonal of the products, bias, clamp
         LAUNCH_B(c, s, "tap_sum", (size_t)B * (L - out_row0) * 36,
-                 q3_launch_tap_sum((const float*)cur, c->conv_out.bias, wav, B, L, c->conv_out.taps, Q3_ACT_CLAMP, s, out_row0));
+                 q3_launch_tap_sum((const float*)cur, c->conv_out.bias, wav, B, L, c->conv_out.taps, Q3_ACT_CLAMP, s, spans ? first_kept : out_row0,
+                                   (const long long*)spans));
     } else {        // final conv to one channel, clamp fused, fp32 samples out
         GemmOpts g; g.act = Q3_ACT_CLAMP; g.row0 = out_row0;
-        TRY(gemm(c, c->conv_out, cur, B, L, wav, L, Q3_F32, g, s));
+        float* dst = spans ? (float*)free_bufs[0] : wav;
+        TRY(gemm(c, c->conv_out, cur, B, L, dst, L, Q3_F32, g, s));
+        if (spans) LAUNCH_B(c, s, "span_copy", (size_t)B * (L - first_kept) * 8, q3_launch_span_copy(dst, B, L, first_kept, (const long long*)spans, wav, s));
     }
     return 0;
 }

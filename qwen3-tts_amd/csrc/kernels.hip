@@ -710,8 +710,9 @@ __global__ void __launch_bounds__(256) replicate_pad_kernel(const T* __restrict_
 // The one-channel causal conv whose per-tap products P[b][m][t] = w_t . z[b][m] a fused unit left behind (8 floats per row):
 // y[b][m] = act(bias + sum_t P[b][m - (taps - 1) + t][t]).  A block stages its 256 rows and the 8 before them in LDS (rows of
 // 9 floats: the diagonal reads of consecutive lanes then fall on distinct banks).
+// spans (or null): item b's samples m_first .. m_first + spans[2b + 1] - 1 go to y + spans[2b] and nothing else is written
 __global__ void __launch_bounds__(256) tap_sum_kernel(const float* __restrict__ P, const float* __restrict__ bias, float* __restrict__ y,
-                                                      int M, int taps, int act, int m_first) {
+                                                      int M, int taps, int act, int m_first, const long long* __restrict__ spans) {
     __shared__ float sm[(256 + 8) * 9];
     const long long b = blockIdx.y;
     const int m0 = m_first + blockIdx.x * 256, tid = threadIdx.x;
@@ -728,7 +729,20 @@ __global__ void __launch_bounds__(256) tap_sum_kernel(const float* __restrict__ 
     float a = bias ? bias[0] : 0.f;
     for (int t = 0; t < taps; ++t) a += sm[(tid + 8 - (taps - 1) + t) * 9 + t];
     if (act == Q3_ACT_CLAMP) a = fminf(1.0f, fmaxf(-1.0f, a));
-    y[b * (long long)M + m] = a;
+    if (spans) {
+        if (m - m_first < spans[2 * b + 1]) y[spans[2 * b] + (m - m_first)] = a;
+    } else {
+        y[b * (long long)M + m] = a;
+    }
+}
+
+// out[spans[2b] + i] = src[b * M + m_first + i] for i < spans[2b + 1]: a forward's kept samples to their places
+__global__ void __launch_bounds__(256) span_copy_kernel(const float* __restrict__ src, int M, int m_first, const long long* __restrict__ spans,
+                                                        float* __restrict__ out) {
+    const long long b = blockIdx.y;
+    const long long n = spans[2 * b + 1], dst = spans[2 * b];
+    const float* s = src + b * (long long)M + m_first;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n && i < M - m_first; i += (long long)gridDim.x * 256) out[dst + i] = s[i];
 }
 
 // The bulk decode's attention in bf16 on the matrix cores (head size 64, window <= 97, no carried rows).  One block = 128
@@ -1337,10 +1351,19 @@ hipError_t q3_launch_replicate_pad(const void* x, void* y, int B, int L, int C, 
     return hipGetLastError();
 }
 
-hipError_t q3_launch_tap_sum(const float* P, const float* bias, float* y, int B, int M, int taps, int act, hipStream_t s, int m_first) {
+hipError_t q3_launch_tap_sum(const float* P, const float* bias, float* y, int B, int M, int taps, int act, hipStream_t s, int m_first,
+                             const long long* spans) {
     if (B == 0 || M == 0) return hipSuccess;
     if (taps < 1 || taps > 8 || B > 65535 || m_first < 0 || m_first >= M) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(tap_sum_kernel, dim3((M - m_first + 255) / 256, B), dim3(256), 0, s, P, bias, y, M, taps, act, m_first);
+    hipLaunchKernelGGL(tap_sum_kernel, dim3((M - m_first + 255) / 256, B), dim3(256), 0, s, P, bias, y, M, taps, act, m_first, spans);
+    return hipGetLastError();
+}
+
+hipError_t q3_launch_span_copy(const float* src, int B, int M, int m_first, const long long* spans, float* out, hipStream_t s) {
+    if (B == 0 || M == 0) return hipSuccess;
+    if (B > 65535 || m_first < 0 || m_first >= M || !spans) return hipErrorInvalidValue;
+    const int gx = std::min((M - m_first + 255) / 256, 4096);
+    hipLaunchKernelGGL(span_copy_kernel, dim3(gx, B), dim3(256), 0, s, src, M, m_first, spans, out);
     return hipGetLastError();
 }
 

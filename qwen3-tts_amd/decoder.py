@@ -251,6 +251,25 @@ class Decoder:
 
     __call__ = forward
 
+    def forward_scatter(self, codes: torch.Tensor, spans: torch.Tensor, out: torch.Tensor, skip_frames: int = 0) -> None:
+        """`forward(codes, skip_frames)` whose kept samples land in place (q3c_forward_scatter): spans is a device int64 tensor
+        [B, 2] of (offset into the flat float32 device tensor `out`, count); item b's samples from skip_frames * total_upsample
+        on, `count` of them, are written at out[offset:], nothing else is.  No per-item copies afterwards."""
+        codes = self._codes_tensor(codes)
+        B, _, T = codes.shape
+        if not 0 <= skip_frames < T:
+            raise ValueError(f"skip_frames must be in [0, {T}), got {skip_frames}")
+        if spans.dtype != torch.int64 or tuple(spans.shape) != (B, 2) or not spans.is_contiguous() or spans.device != self.device:
+            raise ValueError("spans must be a contiguous int64 [B, 2] tensor on the decoder's device")
+        if out.dtype != torch.float32 or not out.is_contiguous() or out.device != self.device:
+            raise ValueError("out must be a contiguous float32 tensor on the decoder's device")
+        with torch.cuda.device(self.device):
+            ws = self._workspace(B, T)
+            base = (ws.data_ptr() + 255) // 256 * 256
+            self._check(self._lib.q3c_forward_scatter(self._ctx, C.c_void_p(codes.data_ptr()), B, T, skip_frames, C.c_void_p(spans.data_ptr()),
+                                                      C.c_void_p(out.data_ptr()), C.c_void_p(base), ws.numel() - (base - ws.data_ptr()),
+                                                      self._stream()))
+
     def forward_static(self, codes: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
         """`forward` for callers that must not allocate device memory: codes [B, Q, T] int64 and `out` [B, 1, T*1920 - 555]
         float32 are device tensors the caller already owns, the workspace is the library's static array
@@ -287,19 +306,36 @@ class Decoder:
         # launch skips the rows only they depend on (forward's skip_frames)
         groups: Dict[Tuple[int, int], List[int]] = {}
         for j, (s, e, ctx) in enumerate(plan):
-            groups.setdefault((e - s, ctx if self.skip_context else 0), []).append(j)
-        for (length, skip), idxs in groups.items():
+            groups.setdefault((e - s, ctx), []).append(j)
+        # every launch writes its chunks' kept samples straight to their places in `out` (forward_scatter): one small table of
+        # (destination, count) per launch row, all launches' tables uploaded in one transfer
+        launches, table = [], []
+        for (length, ctx), idxs in groups.items():
             per = max(1, self.max_frames_per_launch // (length * B))
+            keep = self.cfg.output_length(length) - ctx * up
             for i0 in range(0, len(idxs), per):
                 sub = idxs[i0:i0 + per]
-                stacked = torch.cat([codes[..., plan[j][0]:plan[j][1]] for j in sub], dim=0) if len(sub) > 1 \
-                    else codes[..., plan[sub[0]][0]:plan[sub[0]][1]]
-                wav = self.forward(stacked, skip_frames=skip)
-                for n, j in enumerate(sub):
-                    ctx = plan[j][2]
-                    piece = wav[n * B:(n + 1) * B, :, ctx * up:]
-                    out[:, :, offsets[j]:offsets[j] + piece.shape[-1]] = piece
+                launches.append((ctx, sub, len(table)))
+                for j in sub:
+                    table += [(b * total + offsets[j], keep) for b in range(B)]
+        spans = torch.tensor(table, dtype=torch.int64).reshape(-1, 2).to(self.device)
+        flat = out.view(-1)
+        for ctx, sub, t0 in launches:
+            stacked = torch.cat([codes[..., plan[j][0]:plan[j][1]] for j in sub], dim=0) if len(sub) > 1 \
+                else codes[..., plan[sub[0]][0]:plan[sub[0]][1]]
+            self._forward_kept(stacked, ctx, spans[t0:t0 + len(sub) * B], flat)
         return out
+
+    def _forward_kept(self, codes: torch.Tensor, ctx: int, spans: torch.Tensor, flat: torch.Tensor) -> None:
+        """One launch sequence whose rows drop `ctx` context frames and keep spans[:, 1] samples each, placed at spans[:, 0] of
+        `flat`.  With skip_context off the context's conv-decoder rows are computed as well (same samples, bit for bit)."""
+        if self.skip_context or ctx == 0:
+            self.forward_scatter(codes, spans, flat, skip_frames=ctx)
+        else:                                    # measurement aid: the whole forward, then the placement
+            wav = self.forward(codes)
+            up = self.cfg.total_upsample
+            for n, (dst, cnt) in enumerate(spans.cpu().tolist()):
+                flat[dst:dst + cnt] = wav[n, 0, ctx * up: ctx * up + cnt]
 
     def transformer(self, hidden: torch.Tensor) -> torch.Tensor:
         """The transformer stack alone: hidden states [B, T, latent_dim] (fp32) -> the same shape."""
@@ -450,11 +486,19 @@ class Decoder:
             pad_to = 10 if total_frames >= 4096 * nb10 else 25
         buckets: Dict[Tuple[int, int], List[int]] = {}
         for j, (_i, s, e, ctx, _off) in enumerate(jobs):
-            buckets.setdefault((-(-(e - s) // pad_to) * pad_to, ctx if self.skip_context else 0), []).append(j)
+            buckets.setdefault((-(-(e - s) // pad_to) * pad_to, ctx), []).append(j)
         for (Lb, skip), idxs in sorted(buckets.items()):
             per = max(1, self.max_frames_per_launch // Lb)
             for i0 in range(0, len(idxs), per):
                 launches.append((Lb, skip, idxs[i0:i0 + per]))
+        # where every piece's kept samples go: (offset into `out`, count) per launch row, one table for all launches
+        span_rows, span_off = [], []
+        for Lb, _skip, sub in launches:
+            span_off.append(len(span_rows))
+            for j in sub:
+                i, s, e, ctx, off = jobs[j]
+                span_rows.append((starts[i] + off, self.cfg.output_length(e - s) - ctx * up))
+        spans_host = np.asarray(span_rows, dtype=np.int64).reshape(-1, 2)
         idx_dev, idx_off = None, []
         if flat_codes is not None:
             # every launch's gather indices built up front and copied to the device in ONE transfer: a blocking copy per launch
@@ -469,7 +513,11 @@ class Decoder:
                     i, s, e, _ctx, _off = jobs[j]
                     idx_all[o + n * Lb: o + n * Lb + (e - s)] = np.arange(bases[i] + s, bases[i] + e)
                 o += len(sub) * Lb
-            idx_dev = torch.from_numpy(idx_all).to(self.device)
+            # the gather indices and the placement table cross PCIe as ONE transfer
+            both = torch.from_numpy(np.concatenate([idx_all, spans_host.reshape(-1)])).to(self.device)
+            idx_dev, spans_dev = both[:total_idx], both[total_idx:].view(-1, 2)
+        else:
+            spans_dev = torch.from_numpy(spans_host).to(self.device)
         for k, (Lb, skip, sub) in enumerate(launches):
             if idx_dev is not None:
                 idx = idx_dev[idx_off[k]: idx_off[k] + len(sub) * Lb].view(len(sub), Lb)
@@ -479,11 +527,7 @@ class Decoder:
                 for n, j in enumerate(sub):
                     i, s, e, _ctx, _off = jobs[j]
                     batch[n, :, : e - s] = dev_items[i][:, s:e]
-            wav = self.forward(batch, skip_frames=skip)
-            for n, j in enumerate(sub):
-                i, s, e, ctx, off = jobs[j]
-                keep = self.cfg.output_length(e - s) - ctx * up
-                out[starts[i] + off: starts[i] + off + keep] = wav[n, 0, ctx * up: ctx * up + keep]
+            self._forward_kept(batch, skip, spans_dev[span_off[k]: span_off[k] + len(sub)], out)
         with torch.cuda.device(self.device):
             self._check(self._lib.q3c_check_errors(self._ctx, self._stream()))
         return out, starts, lengths

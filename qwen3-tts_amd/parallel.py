@@ -138,15 +138,82 @@ def decode_long_sharded(decoder, codes: torch.Tensor, chunk_size: int = 300, lef
     mine = chunk_assign(len(plan), world)[rank]
     up = cfg.total_upsample
     local: List[torch.Tensor] = []
-    by_len = {}
+    # chunks of equal length AND equal context share a launch sequence, which then skips the conv-decoder rows under the
+    # context's dropped samples - the same launches a single GPU's chunked_decode makes
+    groups = {}
     for c in mine:
-        by_len.setdefault(plan[c][1] - plan[c][0], []).append(c)
+        groups.setdefault((plan[c][1] - plan[c][0], plan[c][2]), []).append(c)
     pieces = {}
-    for _length, cs in by_len.items():
+    skip_ok = getattr(decoder, "skip_context", False)
+    for (_length, ctx), cs in groups.items():
         batch = torch.stack([codes[:, plan[c][0]:plan[c][1]] for c in cs])
-        wav = decoder.forward(batch)
+        wav = decoder.forward(batch, skip_frames=ctx) if (skip_ok and ctx) else decoder.forward(batch)
         for n, c in enumerate(cs):
-            pieces[c] = wav[n, 0, plan[c][2] * up:]
+            pieces[c] = wav[n, 0, ctx * up:]
     local = [pieces[c] for c in mine]
     out = gather_waveforms(local, mine, len(plan), dst=dst, group=group)
     return None if out is None else np.concatenate(out)
+
+
+# ---- streams over the GPUs of one node ----------------------------------------------------------------------------------
+class StreamRouter:
+    """Which rank owns which stream.  A stream is placed once, when it opens, on the rank with the fewest open streams (lowest
+    rank on ties), and never migrates: its causal state lives in that GPU's memory.  Pure bookkeeping, deterministic, so
+    every rank that sees the same open / close sequence holds the same table and no message is needed to agree on it."""
+
+    def __init__(self, world_size: int, capacity_per_rank: int):
+        self.world, self.capacity = int(world_size), int(capacity_per_rank)
+        self.load = [0] * self.world
+        self.owner = {}
+        self._next = 0
+
+    def open(self) -> int:
+        r = min(range(self.world), key=lambda j: (self.load[j], j))
+        if self.load[r] >= self.capacity:
+            raise RuntimeError(f"every rank's stream pool is full ({self.world} x {self.capacity} slots)")
+        gid = self._next
+        self._next += 1
+        self.owner[gid] = r
+        self.load[r] += 1
+        return gid
+
+    def rank_of(self, gid: int) -> int:
+        return self.owner[gid]
+
+    def close(self, gid: int) -> None:
+        self.load[self.owner.pop(gid)] -= 1
+
+
+class ShardedStreams:
+    """Streams of one node, one `StreamPool` per rank.  Every rank calls open / close / push with the SAME arguments (the
+    front end broadcasts the tick's work list, or every rank reads it from the same queue); a rank only runs the streams it
+    owns, with no collective on the data path.  `push_gather` brings a tick's samples to one rank (or all) with the same
+    point-to-point gather the bulk decode uses."""
+
+    def __init__(self, pool, group=None):
+        self.pool, self.group = pool, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.router = StreamRouter(self.world, pool.capacity)
+        self._local = {}                  # global stream id -> slot in this rank's pool
+
+    def open(self) -> int:
+        gid = self.router.open()
+        if self.router.rank_of(gid) == self.rank:
+            self._local[gid] = self.pool.open()
+        return gid
+
+    def close(self, gid: int) -> None:
+        if self.router.rank_of(gid) == self.rank:
+            self.pool.close_stream(self._local.pop(gid))
+        self.router.close(gid)
+
+    def push(self, gids: Sequence[int], codes: torch.Tensor):
+        """codes [S, Q, n] for the streams `gids` -> (positions in `gids` this rank owns, their new samples)."""
+        mine = [k for k, g in enumerate(gids) if self.router.rank_of(g) == self.rank]
+        if not mine:
+            return mine, []
+        return mine, self.pool.push([self._local[gids[k]] for k in mine], codes[mine])
+
+    def push_gather(self, gids: Sequence[int], codes: torch.Tensor, dst: Optional[int] = 0) -> Optional[List[np.ndarray]]:
+        mine, outs = self.push(gids, codes)
+        return gather_waveforms(outs, mine, len(gids), dst=dst, group=self.group)

@@ -32,7 +32,7 @@ import torch
 from pydantic import BaseModel, Field
 
 from . import audio
-from .batcher import DecodeBatcher
+from .batcher import DecodeBatcher, StreamBatcher
 
 # generation defaults and tables of the reference (config.py:75-107)
 DEFAULT_MAX_NEW_TOKENS = 2048
@@ -123,6 +123,10 @@ class _LockedPcm16Decoder:
             return audio.decode_pcm16(self._dec, encoded)
 
 
+class StreamSlotsBusy(RuntimeError):
+    """Every streaming slot stayed busy for `slot_wait_s`: the SSE route answers 503."""
+
+
 class Engine:
     """One decoder on one GPU behind the server's handlers.
 
@@ -132,17 +136,22 @@ class Engine:
     chunk_frames: code frames per SSE `audio` event (25 frames = 2 s of audio)"""
 
     def __init__(self, decoder, code_source: CodeSource, model_key: str = "base_0.6b", stream_slots: int = 64, chunk_frames: int = 25,
-                 batch_wait_ms: float = 2.0):
+                 batch_wait_ms: float = 2.0, slot_wait_s: float = 30.0):
         self.decoder = decoder
         self.code_source = code_source
         self.models: List[str] = [model_key]
         self.chunk_frames = int(chunk_frames)
+        self.slot_wait_s = float(slot_wait_s)
         self._pool_lock = threading.Lock()         # one context, one pool: every use of the decoder holds this lock
         self.batcher = DecodeBatcher(_LockedPcm16Decoder(decoder, self._pool_lock), max_wait_ms=batch_wait_ms)
         self.pool = decoder.open_streams(stream_slots)
+        # concurrent SSE requests share pushes: one launch sequence per tick for every stream with a chunk pending
+        self.streams = StreamBatcher(self.pool, self._pool_lock, max_wait_ms=batch_wait_ms, to_pcm16=audio.to_pcm16)
+        self._slots = threading.BoundedSemaphore(int(stream_slots))
 
     def close(self) -> None:
         self.batcher.close()
+        self.streams.close()
         self.pool.close()
 
     # model manager surface (reference models.py:108-128)
@@ -164,29 +173,53 @@ class Engine:
         codes = [self.code_source(text=t, seed=s, **kw) for t, s in zip(texts, seeds)]
         return self.batcher.decode(codes)
 
-    # one utterance, chunk by chunk: yields int16 arrays whose concatenation is the whole utterance
-    def synthesize_chunks(self, text: str, seed: Optional[int], **kw) -> Iterator[np.ndarray]:
-        codes = torch.as_tensor(self.code_source(text=text, seed=seed, **kw))
-        Q = self.decoder.cfg.num_quantizers
-        if codes.dim() != 2:
-            raise ValueError(f"code source returned shape {tuple(codes.shape)}, expected [{Q}, T]")
-        if codes.shape[0] != Q:
-            codes = codes.t()
-        T = int(codes.shape[1])
-        if T < 1:
-            raise ValueError("No audio generated")
-        with self._pool_lock:
-            sid = self.pool.open()
+    def acquire_stream(self) -> int:
+        """Claim a streaming slot for one SSE request BEFORE its response starts: when all `stream_slots` are busy the request
+        waits up to `slot_wait_s` (the reference serves such requests one after the other) and then fails with
+        StreamSlotsBusy, which the route answers as HTTP 503 instead of a truncated event stream."""
+        if not self._slots.acquire(timeout=self.slot_wait_s):
+            raise StreamSlotsBusy(f"all {self.pool.capacity} streaming slots are busy")
         try:
+            return self.streams.open()
+        except Exception:
+            self._slots.release()
+            raise
+
+    def release_stream(self, sid: int) -> None:
+        try:
+            self.streams.close_stream(sid)
+        finally:
+            self._slots.release()
+
+    # one utterance, chunk by chunk: yields int16 arrays whose concatenation is the whole utterance
+    def synthesize_chunks(self, text: str, seed: Optional[int], sid: Optional[int] = None, **kw) -> Iterator[np.ndarray]:
+        """`sid`: a slot from acquire_stream, which the CALLER releases; None claims one here and releases it at the end."""
+        own = sid is None
+        if own:
+            sid = self.acquire_stream()
+        try:
+            codes = torch.as_tensor(self.code_source(text=text, seed=seed, **kw))
+            Q = self.decoder.cfg.num_quantizers
+            if codes.dim() != 2:
+                raise ValueError(f"code source returned shape {tuple(codes.shape)}, expected [{Q}, T]")
+            if codes.shape[0] != Q:
+                codes = codes.t()
+            T = int(codes.shape[1])
+            if T < 1:
+                raise ValueError("No audio generated")
+            if T > self.decoder.max_positions:
+                # longer than a stream may run: the whole utterance through the chunked decode, as one piece (the
+                # reference's own stream is one `audio` event, server.py:463-473)
+                pcms, _ = self.batcher.decode([codes])
+                yield pcms[0]
+                return
             for a in range(0, T, self.chunk_frames):
-                with self._pool_lock:
-                    wav = self.pool.push([sid], codes[None, :, a:a + self.chunk_frames], check=True)[0]
-                    pcm = audio.to_pcm16(wav).cpu().numpy()
+                pcm = self.streams.advance(sid, codes[:, a:a + self.chunk_frames])
                 if pcm.size:
                     yield pcm
         finally:
-            with self._pool_lock:
-                self.pool.close_stream(sid)
+            if own:
+                self.release_stream(sid)
 
 
 # ---- handlers (framework-free: create_app binds them) -------------------------------------------------------------------
@@ -252,13 +285,15 @@ def voice_clone_sse(engine: Engine, request: VoiceCloneRequest, model_size: str 
     kw = dict(language=_first(request.language), ref_audio=_first(request.ref_audio), ref_text=_first(request.ref_text),
               x_vector_only_mode=request.x_vector_only_mode, **gen_kwargs)
     sr = engine.decoder.cfg.sample_rate
+    # the slot is claimed here, before the response starts: a full pool is an HTTP error, not a truncated event stream
+    sid = engine.acquire_stream() if streaming else None
 
     def events() -> Iterator[str]:
         t0 = time.time()
         yield sse_event("meta", {"status": "generating", "text": text})
         k = 0
         if streaming:
-            for pcm in engine.synthesize_chunks(text, request.seed, **kw):
+            for pcm in engine.synthesize_chunks(text, request.seed, sid=sid, **kw):
                 yield sse_event("audio", {"chunk_index": k, "audio": audio.audio_to_base64(pcm, sr), "sample_rate": sr,
                                           "generation_time": round(time.time() - t0, 3)})
                 k += 1
@@ -269,7 +304,35 @@ def voice_clone_sse(engine: Engine, request: VoiceCloneRequest, model_size: str 
             k = 1
         yield sse_event("done", {"total_time": round(time.time() - t0, 3), "total_chunks": k}, ascii_only=True)
 
-    return events()
+    return _SlotGuard(events(), engine, sid) if sid is not None else events()
+
+
+class _SlotGuard:
+    """The event stream of a request that holds a streaming slot: the slot goes back exactly once - when the stream ends,
+    fails, is closed by the server (client gone), or is dropped without ever having been started."""
+
+    def __init__(self, it: Iterator[str], engine: "Engine", sid: int):
+        self._it, self._engine, self._sid = it, engine, sid
+
+    def __iter__(self):
+        return self
+
+    def __next__(self) -> str:
+        try:
+            return next(self._it)
+        except BaseException:
+            self.close()
+            raise
+
+    def close(self) -> None:
+        sid, self._sid = self._sid, None
+        if sid is not None:
+            try:
+                self._it.close()
+            finally:
+                self._engine.release_stream(sid)
+
+    __del__ = close
 
 
 # ---- FastAPI binding -----------------------------------------------------------------------------------------------------
@@ -321,6 +384,8 @@ def create_app(engine: Engine):
     def tts_voice_clone_sse(request: VoiceCloneRequest, model_size: str = "0.6b", streaming: bool = True):
         try:
             stream = voice_clone_sse(engine, request, model_size, streaming)
+        except StreamSlotsBusy as e:
+            raise HTTPException(status_code=503, detail=str(e))
         except Exception as e:
             raise HTTPException(status_code=500, detail=str(e))
         return StreamingResponse(stream, media_type="text/event-stream",

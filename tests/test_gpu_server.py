@@ -173,3 +173,93 @@ def test_errors_become_http_500_with_the_message(stack):
     assert r.status_code == 422
     r = client.post("/tts/voice_clone", json={"text": "hi", "generation_params": {"temperature": 3.0}, **REF})
     assert r.status_code == 422
+
+
+def test_concurrent_sse_requests_share_pushes_and_each_gets_its_own_audio():
+    """24 SSE requests at once (reference route: server.py:425-486, which serves them one by one): their chunks advance through
+    SHARED pushes - one launch sequence per tick for every stream with a chunk pending - so the number of pushes is far below
+    requests x chunks, and every request's concatenated audio is still the oracle's un-chunked decode of its own codes."""
+    import threading
+    cfg = q3.tiny_config()
+    w = q3.synthetic_weights(cfg, seed=11)
+    dec = Decoder(cfg, w, device="cuda:0", precision="f32")
+    src = server.hashed_code_source(cfg)
+    eng = server.Engine(dec, src, stream_slots=32, chunk_frames=10, batch_wait_ms=20.0)
+    try:
+        N = 24
+        texts = [("request %02d " % i) + "y" * (20 + 3 * i) for i in range(N)]        # 27 .. 90 frames: 3 .. 9 chunks each
+        results, errors = [None] * N, []
+        gate = threading.Barrier(N)
+
+        def run(i):
+            try:
+                gate.wait()
+                req = server.VoiceCloneRequest(text=texts[i], seed=i, **REF)
+                results[i] = _events("".join(server.voice_clone_sse(eng, req)))
+            except Exception as e:                                      # noqa: BLE001
+                errors.append((i, repr(e)))
+
+        threads = [threading.Thread(target=run, args=(i,)) for i in range(N)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(120)
+        assert not errors, errors
+        total_chunks = 0
+        for i in range(N):
+            ev = results[i]
+            codes = src(text=texts[i], seed=i)
+            n_chunks = -(-codes.shape[1] // eng.chunk_frames)
+            total_chunks += n_chunks
+            audio_ev = [d for n, d in ev if n == "audio"]
+            assert ev[0][0] == "meta" and ev[-1][0] == "done" and ev[-1][1]["total_chunks"] == n_chunks == len(audio_ev)
+            assert [d["chunk_index"] for d in audio_ev] == list(range(n_chunks))
+            got = np.concatenate([_pcm_of_wav_file(base64.b64decode(d["audio"])) for d in audio_ev])
+            _close(got, _want_pcm(cfg, w, [codes], chunked=False)[0])
+        print(f"{N} concurrent SSE requests, {total_chunks} chunks: {eng.streams.pushes} pushes in {eng.streams.ticks} ticks")
+        assert eng.streams.chunks == total_chunks
+        assert eng.streams.pushes <= total_chunks // 4, (eng.streams.pushes, total_chunks)     # measured: ~1/8
+        assert len(eng.pool._frames) == 0                                # every slot went back
+    finally:
+        eng.close()
+
+
+def test_sse_full_pool_is_http_503_and_bad_chunks_stay_with_their_request():
+    from fastapi.testclient import TestClient
+    cfg = q3.tiny_config()
+    dec = Decoder(cfg, q3.synthetic_weights(cfg, seed=11), device="cuda:0", precision="f32", max_positions=320)
+    src = server.hashed_code_source(cfg)
+    eng = server.Engine(dec, src, stream_slots=1, chunk_frames=25, slot_wait_s=0.05)
+    try:
+        client = TestClient(server.create_app(eng))
+        held = eng.acquire_stream()
+        r = client.post("/tts/voice_clone/sse", json={"text": "hello", "seed": 1, **REF})
+        assert r.status_code == 503 and "busy" in r.json()["detail"]
+        eng.release_stream(held)
+        r = client.post("/tts/voice_clone/sse", json={"text": "hello again", "seed": 1, **REF})
+        assert r.status_code == 200 and _events(r.text)[-1][0] == "done"
+        # an utterance longer than a stream may run (max_positions = 320 frames) falls back to one chunked whole-utterance piece
+        long_text = "z" * 400                                            # 360 frames
+        ev = _events(client.post("/tts/voice_clone/sse", json={"text": long_text, "seed": 2, **REF}).text)
+        assert [n for n, _ in ev] == ["meta", "audio", "done"] and ev[-1][1]["total_chunks"] == 1
+        assert len(eng.pool._frames) == 0
+    finally:
+        eng.close()
+    # a chunk with a code outside the code book is refused in its caller's thread; the stream beside it is untouched
+    eng = server.Engine(dec, src, stream_slots=2, chunk_frames=25)
+    try:
+        a, b = eng.streams.open(), eng.streams.open()
+        good = q3.random_codes(cfg, 1, 5, seed=3)[0]
+        bad = good.clone()
+        bad[1, 2] = cfg.codebook_size
+        with pytest.raises(IndexError):
+            eng.streams.submit(a, bad)
+        with pytest.raises(ValueError):
+            eng.streams.submit(a, torch.zeros((cfg.num_quantizers + 1, 3), dtype=torch.int64))
+        fa, fb = eng.streams.submit(a, good), eng.streams.submit(b, good)
+        assert np.array_equal(fa.result(30), fb.result(30)) and fa.result().dtype == np.int16
+        assert fa.result().shape == (5 * cfg.total_upsample - cfg.trim,)
+        eng.streams.close_stream(a)
+        eng.streams.close_stream(b)
+    finally:
+        eng.close()

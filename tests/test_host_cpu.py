@@ -180,7 +180,14 @@ class DeviceStandIn(CpuStandIn):     # the form the GPU decoder offers: samples 
         lens = [len(x) for x in wavs]
         starts = [int(v) for v in np.cumsum([0] + lens[:-1])]
         return torch.cat([torch.from_numpy(x) for x in wavs]), starts, lens
-    def forward(self, codes): return oracle.forward(cfg, w, codes)
+    skip_context = True
+    skips = []
+    def forward(self, codes, skip_frames=0):
+        # q3c_forward_skip: the samples of the first skip_frames frames are not produced (zeros here); the rest are the forward's
+        DeviceStandIn.skips.append(skip_frames)
+        wav = oracle.forward(cfg, w, codes)
+        wav[..., : skip_frames * cfg.total_upsample] = 0.0
+        return wav
 out = decode_sharded(DeviceStandIn(), items, dst=None)
 for a, b in zip(out[0], want):
     assert np.array_equal(a, b)
@@ -190,6 +197,47 @@ want_long = oracle.chunked_decode(cfg, w, long_codes, 5, 2)[0, 0].numpy()
 got_long = decode_long_sharded(DeviceStandIn(), long_codes[0], 5, 2, dst=None)
 assert got_long.shape == want_long.shape == (cfg.chunked_output_length(23, 5, 2),)
 assert np.abs(got_long - want_long).max() <= 1e-4      # fp32 batching noise of the CPU GEMMs is ~2e-5
+# every chunk after the first was launched with its context as skip_frames (the launches a single GPU's chunked_decode makes)
+assert sorted(set(DeviceStandIn.skips)) == ([0, 2] if rank == 0 else [2]), DeviceStandIn.skips
+
+# streams over two ranks: placed on the least-loaded rank when they open, never migrating, no collective on the data path
+from qwen3_tts_amd.parallel import ShardedStreams, StreamRouter
+class CpuPool:                       # a StreamPool stand-in: a push = the un-chunked forward of all frames so far, new samples only
+    def __init__(self, capacity): self.capacity, self.hist, self.done = capacity, {{}}, {{}}
+    def open(self):
+        sid = min(set(range(self.capacity)) - set(self.hist)); self.hist[sid] = None; self.done[sid] = 0; return sid
+    def close_stream(self, sid): del self.hist[sid], self.done[sid]
+    def push(self, ids, codes):
+        out = []
+        for b, sid in enumerate(ids):
+            self.hist[sid] = codes[b:b + 1] if self.hist[sid] is None else torch.cat([self.hist[sid], codes[b:b + 1]], dim=2)
+            wav = oracle.forward(cfg, w, self.hist[sid])[0, 0]
+            out.append(wav[self.done[sid]:].clone()); self.done[sid] = wav.numel()
+        return out
+pool = CpuPool(3)
+ss = ShardedStreams(pool)
+gids = [ss.open() for _ in range(5)]
+assert [ss.router.rank_of(g) for g in gids] == [0, 1, 0, 1, 0] and len(pool.hist) == (3 if rank == 0 else 2)
+sc = q3.random_codes(cfg, 5, 6, seed=33)
+got = [[] for _ in gids]
+for t in range(0, 6, 2):
+    pieces = ss.push_gather(gids, sc[:, :, t:t + 2], dst=None)
+    for k, p_ in enumerate(pieces):
+        got[k].append(p_)
+for k in range(5):
+    want_k = oracle.forward(cfg, w, sc[k:k + 1])[0, 0].numpy()
+    assert np.abs(np.concatenate(got[k]) - want_k).max() <= 1e-4, k
+ss.close(gids[1])                    # rank 1 now holds one stream, rank 0 three: the next two streams open on rank 1
+g5, g6 = ss.open(), ss.open()
+assert ss.router.rank_of(g5) == 1 and ss.router.rank_of(g6) == 1 and ss.router.load == [3, 3]
+try:
+    ss.open(); raise SystemExit("a full node must refuse a stream")
+except RuntimeError as e:
+    assert "full" in str(e)
+only1 = ss.push_gather([g5], q3.random_codes(cfg, 1, 2, seed=5), dst=0)      # a tick whose streams all live on one rank
+assert (only1 is not None and len(only1) == 1 and only1[0].shape == (2 * cfg.total_upsample - cfg.trim,)) if rank == 0 else only1 is None
+r = StreamRouter(4, 2)
+assert [r.rank_of(r.open()) for _ in range(8)] == [0, 1, 2, 3, 0, 1, 2, 3]
 # a rank with nothing to send
 local = [torch.arange(5, dtype=torch.float32)] if rank == 1 else []
 got = gather_waveforms(local, [0] if rank == 1 else [], 1, dst=0)
@@ -518,6 +566,83 @@ def test_batcher_errors_stay_with_their_request():
         assert len(f3.result()[0]) == 2
     with pytest.raises(RuntimeError):
         bat.submit(good)
+
+
+class _FakePool:
+    """What StreamBatcher needs from a StreamPool, on the CPU: a chunk's "samples" are its codes' column sums times the
+    stream's running frame count, so a mix-up of streams or of chunk order shows."""
+
+    def __init__(self, cfg, capacity):
+        import types
+        self.dec = types.SimpleNamespace(cfg=cfg, max_positions=50)
+        self.capacity, self._frames, self.calls = capacity, {}, []
+
+    def open(self):
+        sid = min(set(range(self.capacity)) - set(self._frames))
+        self._frames[sid] = 0
+        return sid
+
+    def close_stream(self, sid):
+        del self._frames[sid]
+
+    def frames_pushed(self, sid):
+        return self._frames[sid]
+
+    def push(self, ids, codes):
+        self.calls.append((list(ids), tuple(codes.shape)))
+        out = []
+        for b, sid in enumerate(ids):
+            out.append((codes[b].sum(0).float() + 1000.0 * self._frames[sid]))
+            self._frames[sid] += codes.shape[2]
+        return out
+
+
+def test_stream_batcher_shares_pushes_between_concurrent_streams():
+    import threading
+    from qwen3_tts_amd.batcher import StreamBatcher
+    cfg = q3.tiny_config()
+    pool = _FakePool(cfg, 16)
+    sb = StreamBatcher(pool, max_wait_ms=200.0)
+    try:
+        N, chunks = 12, 4
+        sids = [sb.open() for _ in range(N)]
+        codes = {s: q3.random_codes(cfg, chunks, 3, seed=s) for s in sids}     # [chunk, Q, 3] per stream
+        got = {s: [] for s in sids}
+
+        def run(s):
+            for k in range(chunks):
+                got[s].append(sb.advance(s, codes[s][k]))
+
+        threads = [threading.Thread(target=run, args=(s,)) for s in sids]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(30)
+        for s in sids:
+            for k in range(chunks):
+                want = (codes[s][k].sum(0).float() + 1000.0 * 3 * k).numpy()
+                assert np.array_equal(got[s][k], want), (s, k)
+        # every tick waited for all open streams (or 200 ms): 12 streams x 4 chunks in about 4 pushes, never one per chunk
+        assert sb.chunks == N * chunks and sb.pushes <= 2 * chunks, (sb.pushes, pool.calls)
+        assert all(len(set(ids)) == len(ids) for ids, _ in pool.calls)          # a stream never appears twice in a push
+        # chunks of different length in one tick: one push per length
+        before = sb.pushes
+        f1, f2, f3 = sb.submit(sids[0], codes[sids[0]][0][:, :2]), sb.submit(sids[1], codes[sids[1]][0]), sb.submit(sids[2], codes[sids[2]][0][:, :2])
+        for s in sids[3:]:
+            sb.close_stream(s)
+        assert f1.result(10).shape == (2,) and f2.result(10).shape == (3,) and f3.result(10).shape == (2,)
+        assert sb.pushes - before <= 3
+        # refusals happen in the caller's thread
+        with pytest.raises(ValueError):
+            sb.submit(sids[0], torch.zeros((cfg.num_quantizers, 40), dtype=torch.int64))        # past max_positions = 50
+        with pytest.raises(IndexError):
+            sb.submit(sids[0], torch.full((cfg.num_quantizers, 1), cfg.codebook_size, dtype=torch.int64))
+        with pytest.raises(ValueError):
+            sb.submit(sids[0], torch.zeros((cfg.num_quantizers + 1, 1), dtype=torch.int64))
+    finally:
+        sb.close()
+    with pytest.raises(RuntimeError):
+        sb.submit(0, torch.zeros((cfg.num_quantizers, 1), dtype=torch.int64))
 
 
 def test_wav_container_and_base64_match_the_oracle():
