@@ -11,6 +11,21 @@
 #include <string>
 #include <vector>
 
+#ifdef Q3C_HOST_DRYRUN
+// Sanitizer build of the HOST side only (tools/sanitize_host.py): "device" memory is host memory, so q3c_finalize's weight
+// repacking, the workspace / stream-state layouts and every argument check run under AddressSanitizer and UBSan on a machine
+// without a GPU.  Nothing is launched in such a build and it is never what the package loads.
+#include <cstdlib>
+static hipError_t dry_malloc(void** p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+alignas(256) static unsigned char dry_static_scratch[4096];
+#define hipMalloc(p, n) dry_malloc((void**)(p), (n))
+#define hipFree(p) (std::free(p), hipSuccess)
+#define hipMemcpy(d, s, n, kind) (std::memcpy((d), (s), (n)), hipSuccess)
+#define hipMemset(d, v, n) (std::memset((d), (v), (n)), hipSuccess)
+#define hipGetDevice(p) (*(p) = 0, hipSuccess)
+#define hipGetSymbolAddress(pp, sym) (*(pp) = (void*)dry_static_scratch, hipSuccess)
+#endif
+
 // Workspace of q3c_forward_static: one array per GPU the library's code object is loaded on, held until the process ends.
 // Host code never uses this name as an address: q3c_finalize asks the runtime for the array's address on the context's
 // device and everything after that goes through the pointer it returned.
@@ -559,6 +574,9 @@ int stream_sequence(q3c_stream_pool* P, int S, int n, bool run, const StreamPlan
     const size_t es = esize(dt);
     size_t off = 0;
     long long st_off = 0;
+    // the layout pass (run == false) has no workspace: offsets are added as integers, never to a null pointer
+    const uintptr_t ws_base = (uintptr_t)ws;
+    auto W = [&](size_t o) { return (char*)(ws_base + o); };
     auto alloc = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
     auto carried = [&](const SBuf& b, int col_off_elems, int cols) {
         Q3CarryDesc d{};
@@ -573,7 +591,7 @@ int stream_sequence(q3c_stream_pool* P, int S, int n, bool run, const StreamPlan
         if (hist) carried(b, carry_col, carry_cols < 0 ? ch : carry_cols);
         return b;
     };
-    auto ptr = [&](const SBuf& b) { return (void*)(ws + b.off); };
+    auto ptr = [&](const SBuf& b) { return (void*)W(b.off); };
     // output / residual placement of a tensor with carried rows, in elements
     auto new_rows_off = [](const SBuf& b) { return (long long)b.hist * b.ch; };
     auto item_stride = [](const SBuf& b) { return (long long)(b.hist + b.rows) * b.ch; };
@@ -581,8 +599,8 @@ int stream_sequence(q3c_stream_pool* P, int S, int n, bool run, const StreamPlan
     const int nb = k.num_upsample_rates;
     const size_t o_pos0 = alloc((size_t)S * 4);
     const size_t o_rs = alloc((size_t)S * 4 * 2 * nb);
-    int* pos0 = (int*)(ws + o_pos0);
-    int* rs_all = (int*)(ws + o_rs);
+    int* pos0 = (int*)W(o_pos0);
+    int* rs_all = (int*)W(o_rs);
     Q3StageStarts st{};
     st.count = 2 * nb;
     {
@@ -599,7 +617,7 @@ int stream_sequence(q3c_stream_pool* P, int S, int n, bool run, const StreamPlan
     const size_t fr = (size_t)S * n;
     const size_t wmax = (size_t)std::max(Lt, H);
     const size_t o_x = alloc(fr * wmax * es), o_nrm = alloc(fr * wmax * es);
-    void* bufA = ws + o_x; void* bufB = ws + o_nrm;
+    void* bufA = W(o_x); void* bufB = W(o_nrm);
 
     // ---- front end ----
     if (k.frontend == Q3C_FRONTEND_MEAN_EMBEDDING) {
@@ -612,9 +630,9 @@ int stream_sequence(q3c_stream_pool* P, int S, int n, bool run, const StreamPlan
         if (run) {
             LAUNCH_B(c, s, "rvq_gather_sum", fr * ((size_t)k.num_quantizers * (8 + k.codebook_dim * 4) + (size_t)c->G * k.codebook_dim * 4),
                      q3_launch_rvq_gather_sum((const long long*)codes, S, k.num_quantizers, n, k.codebook_size, k.codebook_dim,
-                                              c->tables_dev, c->group_start_dev, c->G, (float*)(ws + o_sum), c->err_flag, s));
+                                              c->tables_dev, c->group_start_dev, c->G, (float*)W(o_sum), c->err_flag, s));
             GemmOpts g; g.segmented = true; g.y_off = new_rows_off(qb); g.y_bstride = item_stride(qb);
-            TRY(gemm(c, c->rvq_proj, ws + o_sum, S, n, ptr(qb), n, dt, g, s));
+            TRY(gemm(c, c->rvq_proj, W(o_sum), S, n, ptr(qb), n, dt, g, s));
             GemmOpts g2; g2.segmented = true; g2.x_hist = qb.hist;
             TRY(gemm(c, c->pre_conv, ptr(qb), S, n, bufA, n, dt, g2, s));
         }
@@ -645,15 +663,15 @@ int stream_sequence(q3c_stream_pool* P, int S, int n, bool run, const StreamPlan
         TRY(gemm(c, y.qkv, nrm, S, n, ptr(qkv), n, dt, GemmOpts{}, s));
         Q3KvRing ring{P->state, P->slot_stride, ring_off, slots, P->capacity};
         LAUNCH_B(c, s, "swa_attention", fr * (size_t)(2 * qd + 2 * kvd) * es,
-                 q3_launch_swa_attention(ptr(qkv), ws + o_att, c->cos_t, c->sin_t, S, n, k.num_attention_heads, k.num_key_value_heads,
+                 q3_launch_swa_attention(ptr(qkv), W(o_att), c->cos_t, c->sin_t, S, n, k.num_attention_heads, k.num_key_value_heads,
                                          k.head_dim, k.sliding_window, dt, s, ring_rows, pos0, k.max_positions, &ring, c->tuning));
         GemmOpts o1; o1.scale = y.ls_attn; o1.R = x;
-        TRY(gemm(c, y.o, ws + o_att, S, n, x, n, dt, o1, s));
+        TRY(gemm(c, y.o, W(o_att), S, n, x, n, dt, o1, s));
         LAUNCH_B(c, s, "rmsnorm", 2 * fr * H * es, q3_launch_rmsnorm(x, y.ln2, nrm, (long long)fr, H, k.rms_norm_eps, dt, s));
         GemmOpts o2; o2.act = Q3_ACT_SWIGLU;
-        TRY(gemm(c, y.gu, nrm, S, n, ws + o_mlp, n, dt, o2, s));
+        TRY(gemm(c, y.gu, nrm, S, n, W(o_mlp), n, dt, o2, s));
         GemmOpts o3; o3.scale = y.ls_mlp; o3.R = x;
-        TRY(gemm(c, y.down, ws + o_mlp, S, n, x, n, dt, o3, s));
+        TRY(gemm(c, y.down, W(o_mlp), S, n, x, n, dt, o3, s));
     }
     if (run) LAUNCH_B(c, s, "rmsnorm", 2 * fr * H * es, q3_launch_rmsnorm(x, c->final_norm, nrm, (long long)fr, H, k.rms_norm_eps, dt, s));
     void* cur;
@@ -681,15 +699,15 @@ int stream_sequence(q3c_stream_pool* P, int S, int n, bool run, const StreamPlan
             GemmOpts g0; g0.segmented = true; g0.y_off = new_rows_off(d_in); g0.y_bstride = item_stride(d_in);
             TRY(gemm(c, u.tconv, cur, S, L, ptr(d_in), L, dt, g0, s));
             LAUNCH_B(c, s, "dwconv_ln", 2 * (size_t)S * Lf * Lt * es,
-                     q3_launch_dwconv_ln(ptr(d_in), u.dw_w, u.dw_b, u.ln_w, u.ln_b, ws + o_d, S, Lf, Lt, 7, k.convnext_eps, dt, s, d_in.hist));
+                     q3_launch_dwconv_ln(ptr(d_in), u.dw_w, u.dw_b, u.ln_w, u.ln_b, W(o_d), S, Lf, Lt, 7, k.convnext_eps, dt, s, d_in.hist));
             GemmOpts g1; g1.act = Q3_ACT_GELU;
-            TRY(gemm(c, u.pw1, ws + o_d, S, Lf, ws + o_pw, Lf, dt, g1, s));
+            TRY(gemm(c, u.pw1, W(o_d), S, Lf, W(o_pw), Lf, dt, g1, s));
             GemmOpts g2; g2.segmented = true; g2.scale = u.gamma;
             g2.R = ptr(d_in); g2.r_off = new_rows_off(d_in); g2.r_bstride = item_stride(d_in);
             if (last) { g2.y_off = new_rows_off(conv_in_x); g2.y_bstride = item_stride(conv_in_x); }
-            TRY(gemm(c, u.pw2, ws + o_pw, S, Lf, last ? ptr(conv_in_x) : (void*)(ws + o_next), Lf, dt, g2, s));
+            TRY(gemm(c, u.pw2, W(o_pw), S, Lf, last ? ptr(conv_in_x) : (void*)W(o_next), Lf, dt, g2, s));
         }
-        cur = ws + o_next;
+        cur = W(o_next);
         L = Lf;
     }
 
@@ -712,7 +730,7 @@ int stream_sequence(q3c_stream_pool* P, int S, int n, bool run, const StreamPlan
         // fused units read and write the raw stream only (their [carried | new] tensors ARE the residual stream)
         const size_t o_raw = fuse ? 0 : alloc((size_t)S * Lr * ch * es);
         const size_t o_h = fuse ? 0 : alloc((size_t)S * Lr * ch * es);
-        void* raw = ws + o_raw;
+        void* raw = W(o_raw);
         SBuf u_in = tensor(6 * k.dilations[0], Lr, ch, es);
         if (run) {
             // [previous | new] input rows: group j of r output rows needs rows j-1 and j
@@ -746,8 +764,8 @@ int stream_sequence(q3c_stream_pool* P, int S, int n, bool run, const StreamPlan
                     if (last) { Y = ptr(next); g.y_off = new_rows_off(next); g.y_bstride = item_stride(next); }
                     else { Y = raw; g.Y2 = ptr(next); g.y2_off = new_rows_off(next); g.y2_bstride = item_stride(next); }
                     GemmOpts g1; g1.segmented = true; g1.x_hist = u_in.hist; g1.act = Q3_ACT_SNAKE; g1.epi = &u.a2;
-                    TRY(gemm(c, u.c1, ptr(u_in), S, L, ws + o_h, L, dt, g1, s));
-                    TRY(gemm(c, u.c2, ws + o_h, S, L, Y, L, dt, g, s));
+                    TRY(gemm(c, u.c1, ptr(u_in), S, L, W(o_h), L, dt, g1, s));
+                    TRY(gemm(c, u.c2, W(o_h), S, L, Y, L, dt, g, s));
                 }
             }
             u_in = next;

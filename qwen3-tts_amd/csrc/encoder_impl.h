@@ -117,7 +117,8 @@ int encode_sequence(q3c_ctx* c, int B, int L0, bool run, const float* audio, int
     const size_t es = esize(dt);
     size_t off = 0;
     auto alloc = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
-    auto at = [&](size_t o) { return (void*)(ws + o); };
+    const uintptr_t ws_base = (uintptr_t)ws;       // the layout pass has no workspace: integer offsets, never null-pointer arithmetic
+    auto at = [&](size_t o) { return (void*)(ws_base + o); };
 
     // x: a stage's raw input (its residual block's skip path); e: ELU(x), what the block's first conv reads, in the layout
     // of the stage's strided conv (items padded to whole strides, the padding rows zero).  Each producer writes both.
