@@ -202,7 +202,8 @@ convgemm_kernel(const ConvGemmArgs p) {
     const int x_kb = (xpieces + 63) / 64;
     const size_t XBUF = (size_t)x_kb * 1024;
     const bool last_slice_real = (xi_total - 1) * NW + wave < x_kb;       // this wave's part of the last slice holds staged rows
-    const size_t hs_bytes = (size_t)BM * (BN * sizeof(TA) + 16);
+    // the fused unit's h tile: shared (tile-sized) when several waves split the columns, wave-private 32-row pieces otherwise
+    const size_t hs_bytes = WAVES_N == 1 ? (size_t)NW * 32 * (BN * sizeof(TA) + 16) : (size_t)BM * (BN * sizeof(TA) + 16);
     // single-tap layers (k = 1 convs, linears) use a fresh input tile every step: three buffers, fetched two steps
     // ahead like the weights; multi-tap layers keep a tile for `taps` steps: two buffers, the next one filled in slices
     // layers of two or three taps also get three (when they fit): their chunks are too short to hide an HBM fetch
@@ -210,7 +211,7 @@ convgemm_kernel(const ConvGemmArgs p) {
     // LDS map: three weight buffers, then the input buffers.  The fused unit's h tile starts at the THIRD weight buffer
     // (its second contraction cycles through the first two only) and runs over the input buffers, idle by then.
     const size_t main_bytes = 3 * WBUF + round_kb(nxb * XBUF);
-    const size_t fuse_bytes = 2 * WBUF + round_kb(hs_bytes);
+    const size_t fuse_bytes = (WAVES_N == 1 ? 3 : 2) * WBUF + round_kb(hs_bytes);
 
     unsigned char* Ws0 = smem;                       // three weight buffers
     unsigned char* Xs0 = smem + 3 * WBUF;            // the input buffers
@@ -823,7 +824,82 @@ convgemm_kernel(const ConvGemmArgs p) {
     if constexpr (FUSE2) { if (full) r_fetch_full(0); else r_fetch(0, rpre); }
 
     // ---- fused second contraction (k = 1): h = snake(acc + bias) -> LDS -> acc = h . W2^T -------------------------
-    if (FUSE2) {
+    if constexpr (FUSE2 && WAVES_N == 1) {
+        // One column of waves: a wave's second contraction consumes exactly the h rows that wave produced, so the h tile is
+        // WAVE-PRIVATE - 32 rows at a time (one row tile i of the wave), written, read back as the A operand and overwritten by
+        // the next row tile without any workgroup barrier - and 6.5 KB per wave instead of a tile-sized overlay.  The W2 chunk
+        // tiles go into the three weight buffers together (all of W2 when it has at most three chunks: one barrier, before the
+        // first MFMA; wider K in groups of three).
+        constexpr int HLD = BN * (int)sizeof(TA) + 16;              // padded row stride (compile-time: row offsets are immediates)
+        unsigned char* Hw = smem + 3 * WBUF + (size_t)wave * (32 * HLD);   // over the input buffers, idle now
+        const TA* __restrict__ W2 = (const TA*)p.W2;
+        const bool w2_dma = (p.N % BK) == 0;
+        const int nkc2 = (p.N + BK - 1) / BK;
+        auto w2_group = [&](int g0) {               // chunks g0 .. g0 + 2 -> weight buffers 0 .. 2 (the caller has made the ring free)
+            for (int q = 0; q < 3 && g0 + q < nkc2; ++q) {
+                if (w2_dma) w_dma_issue(ws_lds + (unsigned)(q * WBUF), W2 + (long long)(g0 + q) * BK, w2voff);
+                else {
+#pragma unroll
+                    for (int it = 0; it < WITER; ++it) w_store(Ws0 + (size_t)q * WBUF, tid + it * NTHR, w_load(W2, p.N, tid + it * NTHR, g0 + q, 0));
+                }
+            }
+        };
+        w2_group(0);                                // in flight while the first h rows are produced
+        bool first = true;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const int n = j * 32 + l31;
+                const bool nv = n < p.N;
+                const float ea = ia[j], eib = iib[j];           // the unit's inner activation is always SnakeBeta
+                unsigned char* hcol = Hw + (size_t)(4 * half) * HLD + n * sizeof(TA);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = q3_snake<TA>(acc[i][j][r] + ibias[j], ea, eib);
+                    if (nv) *(TA*)(hcol + ((r & 3) + 8 * (r >> 2)) * HLD) = q3_from_f32<TA>(v);
+                    acc[i][j][r] = 0.f;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's h rows are in LDS (its own reads follow)
+            __builtin_amdgcn_wave_barrier();
+            for (int g0 = 0; g0 < nkc2; g0 += 3) {
+                if (!(first || nkc2 <= 3)) {            // a wider K: the ring is reloaded per group, for every row tile
+                    __syncthreads();
+                    w2_group(g0);
+                }
+                if (first || nkc2 > 3) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    if (first) { mark(3); column_params(); }
+                    first = false;
+                }
+                for (int q = 0; q < 3 && g0 + q < nkc2; ++q) {
+                    const unsigned char* ws = Ws0 + (size_t)q * WBUF;
+#pragma unroll
+                    for (int kg = 0; kg < KG; ++kg) {
+                        const int c = kg * 2 + half;
+                        const int kbyte = (g0 + q) * BKB + c * 16;
+                        // columns past N (a K tail of the last chunk) multiply zero-filled weight columns; read them as zero too
+                        const uint4 af = (w2_dma || kbyte < p.N * (int)sizeof(TA)) ? *(const uint4*)(Hw + (size_t)l31 * HLD + kbyte)
+                                                                                   : make_uint4(0, 0, 0, 0);
+                        uint4 bfr[WN];
+#pragma unroll
+                        for (int j = 0; j < WN; ++j) {
+                            const int row = j * 32 + l31;
+                            bfr[j] = *(const uint4*)(ws + (size_t)row * BKB + swz<CPR>(row, c) * 16);
+                        }
+#pragma unroll
+                        for (int j = 0; j < WN; ++j) Mma<TA>::run(af, bfr[j], acc[i][j]);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the A fragments are in registers before the next row tile overwrites them
+            __builtin_amdgcn_wave_barrier();
+        }
+        // the epilogue's slabs overlay the weight buffers: every wave must be done reading W2
+        __syncthreads();
+    } else if (FUSE2) {
         constexpr int HLD = BN * (int)sizeof(TA) + 16;              // padded row stride of the h tile (compile-time: row offsets are immediates)
         unsigned char* Hs = smem + 2 * WBUF;                        // overlays the third weight buffer and the input buffers, idle now
         const TA* __restrict__ W2 = (const TA*)p.W2;
@@ -1278,7 +1354,10 @@ hipError_t launch_cfg(const ConvGemmArgs& a_in, hipStream_t s) {
     // a third input buffer is not worth a CU's second block
     if (a.nxb == 3 && a.taps > 1 && round_kb(3 * xbuf) + wring > 80 * 1024 && round_kb(2 * xbuf) + wring <= 80 * 1024) a.nxb = 2;
     size_t lds = wring + round_kb(a.nxb * xbuf);
-    if (FUSE2) lds = std::max(lds, 2 * wbuf + round_kb((size_t)BM * (BN * sizeof(TA) + 16)) + 1024);   // h tile over the third weight buffer and the input buffers
+    // the fused unit's h tile: over the third weight buffer and the input buffers; wave-private 32-row pieces behind the whole
+    // ring when one column of waves covers every channel
+    if (FUSE2) lds = std::max(lds, WAVES_N == 1 ? 3 * wbuf + round_kb((size_t)NW * 32 * (BN * sizeof(TA) + 16)) + 1024
+                                                : 2 * wbuf + round_kb((size_t)BM * (BN * sizeof(TA) + 16)) + 1024);
     if (FUSE2) lds += round_kb((size_t)2 * a.K * sizeof(float));       // the input SnakeBeta's parameters, behind the spare KiB
     lds = std::max(lds, (size_t)NW * 2 * 16 * (32 * JG + 4) * sizeof(float));    // two wave-private 16-row epilogue slabs per wave
     if (lds > 160 * 1024) return hipErrorInvalidValue;

@@ -1247,12 +1247,91 @@ hipError_t q3_launch_rmsnorm(const void* x, const float* w, void* y, long long r
     return hipGetLastError();
 }
 
+// The same operation with the input read about once: a block walks RT consecutive rows of one item and keeps the K - 1 rows a
+// depthwise tap looks back into in registers, so a row is fetched by one block (plus K - 1 rows of overlap per RT) instead of by
+// the K blocks whose windows contain it - whose workgroups, dealt round-robin over the eight XCDs, each pulled it into their
+// own L2.  Same arithmetic per element and the same reduction order as dwconv_ln_kernel: bit-identical results.
+template <typename T, int CPT, int K, int RT>
+__global__ void __launch_bounds__(256) dwconv_ln_rows_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, const float* __restrict__ lnw,
+                                                             const float* __restrict__ lnb, T* __restrict__ y, int L, int C,
+                                                             float eps, int hist) {
+    __shared__ float red[2][8];
+    const int tid = threadIdx.x, b = blockIdx.y, t0 = blockIdx.x * RT;
+    const T* xb = x + ((long long)b * (hist + L) + hist) * C;
+    T* yb = y + (long long)b * L * C;
+    float wk[K][CPT], bs[CPT], gw[CPT], gb[CPT], win[K][CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int c = tid + i * 256;
+        const bool ok = c < C;
+        bs[i] = ok ? bias[c] : 0.f; gw[i] = ok ? lnw[c] : 0.f; gb[i] = ok ? lnb[c] : 0.f;
+#pragma unroll
+        for (int j = 0; j < K; ++j) wk[j][i] = ok ? w[j * C + c] : 0.f;
+#pragma unroll
+        for (int j = 0; j < K - 1; ++j) {        // rows t0 - (K - 1) + j: carried rows, or zeros before the sequence
+            const int tt = t0 - (K - 1) + j;
+            win[j + 1][i] = (ok && tt >= -hist) ? q3_to_f32(xb[(long long)tt * C + c]) : 0.f;
+        }
+    }
+    const int rows = min(RT, L - t0);
+    for (int r = 0; r < rows; ++r) {
+        const int t = t0 + r, p = r & 1;
+        float v[CPT], s = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = tid + i * 256;
+#pragma unroll
+            for (int j = 0; j < K - 1; ++j) win[j][i] = win[j + 1][i];
+            win[K - 1][i] = c < C ? q3_to_f32(xb[(long long)t * C + c]) : 0.f;
+            float a = 0.f;
+            if (c < C) {
+                a = bs[i];
+#pragma unroll
+                for (int j = 0; j < K; ++j)
+                    if (t - (K - 1) + j >= -hist) a += wk[j][i] * win[j][i];
+                s += a;
+            }
+            v[i] = a;
+        }
+        s = wave_sum(s);
+        if ((tid & 63) == 0) red[p][tid >> 6] = s;
+        __syncthreads();
+        const float mean = (red[p][0] + red[p][1] + red[p][2] + red[p][3]) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = tid + i * 256;
+            if (c < C) { const float d = v[i] - mean; q += d * d; }
+        }
+        q = wave_sum(q);
+        if ((tid & 63) == 0) red[p][4 + (tid >> 6)] = q;
+        __syncthreads();
+        const float rstd = rsqrtf((red[p][4] + red[p][5] + red[p][6] + red[p][7]) / (float)C + eps);
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = tid + i * 256;
+            if (c < C) yb[(long long)t * C + c] = q3_from_f32<T>((v[i] - mean) * rstd * gw[i] + gb[i]);
+        }
+    }
+}
+
 hipError_t q3_launch_dwconv_ln(const void* x, const float* w, const float* b, const float* lnw, const float* lnb, void* y, int B,
                                int L, int C, int k, float eps, int dtype, hipStream_t s, int hist) {
     if (hist < 0) return hipErrorInvalidValue;
     long long rows = (long long)B * L;
     if (rows == 0) return hipSuccess;
     if (C > 256 * 8) return hipErrorInvalidValue;
+    // the usual case (kernel 7, up to 1024 channels, rows enough to fill the chip in 32-row walks): the input is read ~once
+    if (k == 7 && C <= 1024 && B <= 65535 && rows >= 32 * 512) {
+        constexpr int RT = 32;
+        dim3 g2((unsigned)((L + RT - 1) / RT), (unsigned)B);
+        if (dtype == Q3_BF16)
+            hipLaunchKernelGGL((dwconv_ln_rows_kernel<bf16, 4, 7, RT>), g2, dim3(256), 0, s, (const bf16*)x, w, b, lnw, lnb, (bf16*)y, L, C, eps, hist);
+        else
+            hipLaunchKernelGGL((dwconv_ln_rows_kernel<float, 4, 7, RT>), g2, dim3(256), 0, s, (const float*)x, w, b, lnw, lnb, (float*)y, L, C, eps, hist);
+        return hipGetLastError();
+    }
     dim3 grid((unsigned)rows);
 #define Q3_DW(TT, CPT) hipLaunchKernelGGL((dwconv_ln_kernel<TT, CPT>), grid, dim3(256), 0, s, (const TT*)x, w, b, lnw, lnb, (TT*)y, L, C, k, eps, hist)
     const int cpt = (C + 255) / 256;

@@ -399,7 +399,10 @@ class Decoder:
         with torch.cuda.device(self.device):
             need = C.c_size_t()
             self._check(self._lib.q3c_encode_workspace_bytes(self._ctx, B, L, C.byref(need)))
-            ws = torch.empty(need.value + 256, dtype=torch.uint8, device=self.device)
+            ws = self._ws                             # one workspace per decoder, shared with the decode direction: grown, never shrunk
+            if ws is None or ws.numel() < need.value + 256:
+                self._ws = None
+                ws = self._ws = torch.empty(need.value + 256, dtype=torch.uint8, device=self.device)
             base = (ws.data_ptr() + 255) // 256 * 256
             self._check(self._lib.q3c_encode(self._ctx, C.c_void_p(a.data_ptr()), B, L, C.c_void_p(codes.data_ptr()),
                                              C.c_void_p(emb.data_ptr()) if emb is not None else None, C.c_void_p(base), need.value,

@@ -485,3 +485,29 @@ def test_one_launch_unit_at_384_channels_matches_two_launches():
     for tag, got in (("two launches", two), ("one launch", one)):
         assert max_abs(want, got) <= BF16_CHAIN_REL * max(top, 1.0), (tag, max_abs(want, got), top)
 
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_depthwise_conv_layernorm_row_walking_kernel_equals_the_per_row_kernel(precision):
+    """ConvNeXt block on enough rows (8 x 2300 >= 16 384) that its depthwise conv + LayerNorm runs the kernel that walks 32
+    consecutive rows per block with the look-back rows in registers: against the oracle, and bit for bit against the per-row
+    kernel, which the same items take when they are decoded one at a time (2300 rows each).  2300 is not a multiple of 32: the
+    last block of every item is partial, the first one starts in the zero padding."""
+    from qwen3_tts_amd import decoder as D
+    g = torch.Generator().manual_seed(17)
+    rnd = lambda *shape, s=1.0: torch.randn(*shape, generator=g) * s
+    C, B, L = 64, 8, 2300
+    w = {"cn.dwconv.conv.weight": rnd(C, 1, 7, s=7 ** -0.5), "cn.dwconv.conv.bias": rnd(C, s=0.1), "cn.norm.weight": 1.0 + rnd(C, s=0.1),
+         "cn.norm.bias": rnd(C, s=0.1), "cn.pwconv1.weight": rnd(4 * C, C, s=C ** -0.5), "cn.pwconv1.bias": rnd(4 * C, s=0.1),
+         "cn.pwconv2.weight": rnd(C, 4 * C, s=(4 * C) ** -0.5), "cn.pwconv2.bias": rnd(C, s=0.1), "cn.gamma": torch.full((C,), 0.5)}
+    x = rnd(B, C, L)
+    xd = x.permute(0, 2, 1).contiguous().cuda()
+    want = oracle.convnext_block(x, w, "cn.").permute(0, 2, 1).numpy()
+    got = D.convnext_block(xd, w, "cn.", precision=precision).cpu()
+    top = float(np.abs(want).max())
+    err = max_abs(want, got)
+    print(f"convnext block, {B} x {L} rows, {precision}: max|err| {err:.3e} of max|y| {top:.2f}")
+    assert err <= (2e-5 if precision == "f32" else BF16_CHAIN_REL) * max(top, 1.0)
+    for b in (0, 5):
+        alone = D.convnext_block(xd[b:b + 1], w, "cn.", precision=precision).cpu()
+        assert torch.equal(alone[0], got[b]), (b, max_abs(alone[0], got[b]))

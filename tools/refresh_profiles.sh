@@ -6,9 +6,10 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/refresh
 rm -rf $O; mkdir -p $O && cd $R || exit 1
 export TMPDIR=/tmp
-timeout -k 10 300 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > $O/pytest_gpu.txt 2>&1 &&
+timeout -k 10 400 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > $O/pytest_gpu.txt 2>&1 &&
 timeout -k 10 400 python bench.py > $O/bench.json 2> $O/bench.err &&
 timeout -k 10 200 python bench.py --workload stream --steps 300 --warmup 30 > $O/stream.json 2> $O/stream.err &&
+timeout -k 10 300 python bench.py --workload stream --sweep 256,1024,4096,8192 --steps 300 --warmup 30 > $O/stream_sweep.json 2> $O/stream_sweep.err &&
 timeout -k 10 200 python bench.py --workload longform --steps 3 --warmup 1 > $O/longform.json 2> $O/longform.err &&
 timeout -k 10 300 python bench.py --workload mixed --utterances 2000 --steps 1 --warmup 1 > $O/mixed.json 2> $O/mixed.err &&
 timeout -k 10 300 python tools/layer_profile.py > $O/layers.txt 2>&1 &&
