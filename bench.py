@@ -69,7 +69,7 @@ PMC_TRAFFIC = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written by 
 
 def pmc_traffic(variant: str):
     """HBM bytes per launch of a contraction-kernel variant from the committed PMC passes (None if not collected)."""
-    m = __import__("re").match(r"convgemm<(\w+),(\w+),(resunit )?(\d+)x(\d+),k(\d+)B,(\d)w>", variant)
+    m = __import__("re").match(r"convgemm<(\w+),(\w+),(resunit )?(\d+)x(\d+),k(\d+)B,(\d+)w>", variant)
     if not m or not os.path.exists(PMC_TRAFFIC):
         return None
     ta, to, fused, bm, bn, kb, nw = m.groups()
@@ -77,7 +77,8 @@ def pmc_traffic(variant: str):
     # (rows, columns, waves, fused) -> the kernel template's wave grid and per-wave tile counts
     shapes = {("256", "96", "4", False): (4, 1, 2, 3), ("256", "128", "8", False): (4, 2, 2, 2), ("128", "128", "4", False): (2, 2, 2, 2),
               ("256", "32", "4", False): (4, 1, 2, 1), ("256", "64", "8", False): (8, 1, 1, 2), ("256", "256", "8", False): (4, 2, 2, 4), ("256", "192", "8", False): (4, 2, 2, 3),
-              ("256", "192", "8", True): (4, 2, 2, 3), ("128", "192", "4", True): (2, 2, 2, 3), ("256", "96", "4", True): (4, 1, 2, 3), ("256", "32", "4", True): (4, 1, 2, 1)}
+              ("256", "192", "8", True): (4, 2, 2, 3), ("128", "192", "4", True): (2, 2, 2, 3), ("256", "96", "4", True): (4, 1, 2, 3), ("256", "32", "4", True): (4, 1, 2, 1),
+              ("768", "96", "12", True): (12, 1, 2, 3)}
     sh = shapes.get((bm, bn, nw, bool(fused)))
     if sh is None:
         return None

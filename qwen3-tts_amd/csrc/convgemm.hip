@@ -16,7 +16,7 @@ int q3_convgemm_fusable(int N, int dtype, int tuning) { return N <= (dtype == Q3
 const char* q3_convgemm_variant(const ConvGemmArgs& a, int in_dtype, int out_dtype) {
     static const char* shapes[SH_COUNT] = {"256x96,k64B,4w", "256x128,k128B,8w", "128x128,k128B,4w", "128x128,k64B,4w", "256x32,k64B,4w",
                                            "resunit 256x192,k64B,8w", "resunit 256x96,k64B,4w", "resunit 256x32,k64B,4w",
-                                           "256x128,k64B,8w", "resunit 128x192,k64B,4w", "resunit 128x384,k64B,8w", "256x64,k64B,8w", "128x32,k128B,4w", "128x64,k128B,4w"};
+                                           "256x128,k64B,8w", "resunit 128x192,k64B,4w", "resunit 128x384,k64B,8w", "256x64,k64B,8w", "128x32,k128B,4w", "128x64,k128B,4w", "resunit 768x96,k64B,12w"};
     static const char* types[4] = {"f32,f32", "bf16,bf16", "f32,bf16", "bf16,f32"};
     static char names[4][SH_COUNT][64];
     const int t = (in_dtype == Q3_F32 && out_dtype == Q3_F32) ? 0 : (in_dtype == Q3_BF16 ? (out_dtype == Q3_BF16 ? 1 : 3) : 2);

@@ -105,6 +105,8 @@ __device__ __forceinline__ void block_barrier() {
 // waves per SIMD, 128 registers each); every other shape two waves per SIMD.
 template <typename TA, typename TO, int NW, int WM, int WN, int BKB, bool FUSE2> constexpr int waves_per_simd() {
     // fp32 operands or outputs (the parity path, taps) need more than 128 registers in that shape: one block per CU there
+    // the twelve-wave fused unit (768 rows, one block per CU): three waves per SIMD, 168 registers each
+    if (FUSE2 && NW == 12) return 3;
     return (sizeof(TA) == 2 && sizeof(TO) == 2 && NW == 8 && !FUSE2 && BKB == 64 && WM * WN <= 4) ? 4 : 2;
 }
 
@@ -122,12 +124,12 @@ convgemm_kernel(const ConvGemmArgs p) {
     constexpr int WPIECES = BN * CPR;
     constexpr int WITER = (WPIECES + NTHR - 1) / NTHR;
     constexpr size_t WBUF = round_kb((size_t)BN * BKB);
-    static_assert(NW == 4 || NW == 8, "4 or 8 waves per block");
+    static_assert(NW == 4 || NW == 8 || NW == 12, "4, 8 or 12 waves per block");
     static_assert(NTHR % CPR == 0, "column chunk of a thread is fixed");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63;
+    int tid = threadIdx.x, lane = tid & 63;          // (re-derived after the main loop by the lean-register shapes)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     // 1-D tile index with the N tiles fastest.  Workgroups are dealt round-robin over the 8 XCDs (each with its own
@@ -319,6 +321,7 @@ convgemm_kernel(const ConvGemmArgs p) {
             *pp = v;
         }
     };
+    int late0 = 0;                       // see after the main loop
     unsigned wvoff[WITER], w2voff[WITER];
 #pragma unroll
     for (int q = 0; q < WITER; ++q) {
@@ -329,6 +332,16 @@ convgemm_kernel(const ConvGemmArgs p) {
         wvoff[q] = (unsigned)((n * p.K + swz<CPR>(row, cs) * EPC) * (int)sizeof(TA));
         w2voff[q] = (unsigned)((n * p.N + swz<CPR>(row, cs) * EPC) * (int)sizeof(TA));
     }
+    auto w2voff_late = [&]() {           // the same offsets recomputed where they are used (lean-register shapes: not carried through the main loop)
+#pragma unroll
+        for (int q = 0; q < WITER; ++q) {
+            const int id = (q * NW + wave) * 64 + lane;
+            const int row = id / CPR, cs = id % CPR;
+            int n = n0 + row;
+            n = n < p.N ? n : p.N - 1;
+            w2voff[q] = (unsigned)((n * p.N + swz<CPR>(row, cs) * EPC) * (int)sizeof(TA)) + (unsigned)late0;
+        }
+    };
     auto w_dma_one = [&](unsigned ws, const TA* sbase, const unsigned* voff, int q) {
         if (WITER * NW * 64 == WPIECES || (q * NW + wave) * 64 < WPIECES) dma16_so(sbase, voff[q], ws + (unsigned)(q * NW + wave) * 1024u);
         else dma16_so(zero_page, 0u, spare_lds);
@@ -384,9 +397,18 @@ convgemm_kernel(const ConvGemmArgs p) {
     // The fused unit's inner bias and SnakeBeta parameters are fetched HERE and pinned right after the main loop (where
     // the DMA queue is empty): fetched after the main loop, the compiler's wait for them is a vmcnt(0) that also waits
     // for the residual rows and the W2 tile requested just before - a round trip to HBM in front of the inner activation.
+    // Shapes that run three waves per SIMD have 168 registers per lane.  NOTHING may spill in this kernel: the rows and
+    // parameters requested through inline asm are in flight without the compiler knowing, and a register it spills and hands to
+    // another value while such a load is pending gets overwritten when the load lands.  So these shapes keep less in
+    // registers: the inner activation's parameters wait in LDS ([BN] frequencies, [BN] gains, [BN] biases behind the input
+    // SnakeBeta's, zeros past N; an LDS read involves no vmcnt), residual rows are requested one pass later, and the folded
+    // final conv reads its taps per pass.
+    constexpr bool LEAN_REGS = waves_per_simd<TA, TO, NW, WM, WN, BKB, FUSE2>() == 3;
+    constexpr bool INNER_LDS = FUSE2 && WAVES_N == 1 && LEAN_REGS;
+    float* inn_lds = pre_lds + 2 * p.K;
     float ia[WN], iib[WN], ibias[WN];                           // the fused unit's inner bias and SnakeBeta
     auto inner_params = [&]() {                                 // called behind the prologue's requests: the first tiles go first
-        if constexpr (FUSE2) {
+        if constexpr (FUSE2 && !INNER_LDS) {
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
                 const int n = wn * 32 * WN + j * 32 + (lane & 31);
@@ -424,6 +446,14 @@ convgemm_kernel(const ConvGemmArgs p) {
             const float* src = q < (npre4 >> 1) ? p.pre_a + 4 * q : p.pre_invb + 4 * (q - (npre4 >> 1));
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ppre) : "v"(src) : "memory");
         }
+        u32x4 pinn;
+        constexpr int ninn4 = 3 * BN / 4;                                // float4 pieces of [BN a | BN invb | BN bias]
+        if constexpr (INNER_LDS) {      // every lane loads (a piece past N or of a missing bias: the zero page): no branch around the request
+            const int q = tid < ninn4 ? tid : 0, arr = q / (BN / 4), n4 = 4 * (q - arr * (BN / 4));
+            const float* base = arr == 0 ? p.epi_a : (arr == 1 ? p.epi_invb : p.bias);
+            const float* src = (base != nullptr && n4 < p.N) ? base + n4 : (const float*)p.zeros;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pinn) : "v"(src) : "memory");
+        }
         for (int it = 0; it < xi_total; ++it) x_dma_issue(xs_lds, it, 0);
         w_dma_issue(ws_lds, Wg, wvoff);
         inner_params();
@@ -438,6 +468,10 @@ convgemm_kernel(const ConvGemmArgs p) {
         if constexpr (FUSE2) {      // parameters -> LDS, published by a barrier of their own, then chunk 0 of the input tile
             asm volatile("" : "+v"(ppre));
             if (tid < npre4) *(u32x4*)(pre_lds + 4 * tid) = ppre;
+            if constexpr (INNER_LDS) {
+                asm volatile("" : "+v"(pinn));
+                if (tid < ninn4) *(u32x4*)(inn_lds + 4 * tid) = pinn;
+            }
             block_barrier();
             for (int it = 0; it < xi_total; ++it) x_snake(Xs0, it, 0);
         }
@@ -583,7 +617,7 @@ convgemm_kernel(const ConvGemmArgs p) {
             auto chunk = [&](auto last_tag, const unsigned char* xs, unsigned xsn, const TA* xnext, unsigned char* xs_next, int kc_next) {
                 // With 128 registers per wave the seven taps' fragment addresses must not be kept across chunks (they
                 // spill, and a reload's wait drains the DMA queue): hide the tap offset's loop invariance from the compiler.
-                if constexpr (waves_per_simd<TA, TO, NW, WM, WN, BKB, FUSE2>() == 4) asm volatile("" : "+s"(off_step));
+                if constexpr (waves_per_simd<TA, TO, NW, WM, WN, BKB, FUSE2>() >= 3) asm volatile("" : "+s"(off_step));
                 one(std::integral_constant<int, 0>{}, last_tag, xs, xsn, xnext, xs_next, kc_next);
                 one(std::integral_constant<int, 1>{}, last_tag, xs, xsn, xnext, xs_next, kc_next);
                 one(std::integral_constant<int, 2>{}, last_tag, xs, xsn, xnext, xs_next, kc_next);
@@ -701,6 +735,13 @@ convgemm_kernel(const ConvGemmArgs p) {
     } else {
         // ---- K tail (narrow test shapes): synchronous register staging, zero-filled past K ----
         inner_params();
+        if constexpr (INNER_LDS) {          // published by the loop's barriers (there is at least one step)
+            for (int idx = tid; idx < 3 * BN; idx += NTHR) {
+                const int arr = idx / BN, n = idx - arr * BN;
+                const float* base = arr == 0 ? p.epi_a : (arr == 1 ? p.epi_invb : p.bias);
+                inn_lds[idx] = (base != nullptr && n < p.N) ? base[n] : 0.f;
+            }
+        }
         int kc = 0, tap = 0;
         for (int step = 0; step < nsteps; ++step) {
             if (tap == 0)
@@ -714,9 +755,17 @@ convgemm_kernel(const ConvGemmArgs p) {
         }
     }
 
+    if constexpr (LEAN_REGS) {
+        // the lane number from the execution mask counters instead of a register carried through the main loop
+        lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        tid = wave * 64 + lane;
+    }
     const int half = lane >> 5, l31 = lane & 31;
     mark(2);
-    if constexpr (FUSE2) {      // the compiler's wait for the parameters lands here, where the DMA queue is empty
+    // lean-register shapes: the epilogue's per-lane row offsets must not be computed before the main loop and carried through
+    // it (they are loop-invariant, so the compiler would): an opaque zero defined HERE goes into every one of them
+    if constexpr (LEAN_REGS) asm volatile("" : "+v"(late0));
+    if constexpr (FUSE2 && !INNER_LDS) {      // the compiler's wait for the parameters lands here, where the DMA queue is empty
 #pragma unroll
         for (int j = 0; j < WN; ++j) asm volatile("" : "+v"(ia[j]), "+v"(iib[j]), "+v"(ibias[j]));
     }
@@ -788,14 +837,14 @@ convgemm_kernel(const ConvGemmArgs p) {
     u32x4 rpre[NPIECE];
     // second set of rows in flight, for the fused unit's late residual add (below): there the rows of pass p are consumed at
     // the END of pass p, so the request for pass p + 1 needs registers of its own to be a whole pass ahead
-    u32x4 rpre2[FUSE2 ? NPIECE : 1];
+    u32x4 rpre2[(FUSE2 && !LEAN_REGS) ? NPIECE : 1];
     auto r_fetch_into = [&](int pass, u32x4* dst) {
         const int rh = pass & 1, q = pass >> 1, jgi = q % (WN / JG), i = q / (WN / JG);
 #pragma unroll
         for (int k = 0; k < NPIECE; ++k) {
             const int id = lane + 64 * k;
             const int row = id / CPRW_F, ch = id - row * CPRW_F;
-            const int m = m0 + wm * 32 * WM + i * 32 + rh * 16 + row;
+            const int m = m0 + wm * 32 * WM + i * 32 + rh * 16 + row + late0;
             const int n = n0 + wn * 32 * WN + jgi * JG * 32 + ch * EPO;
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[k]) : "v"(Rb + (long long)m * p.ldr + n) : "memory");
         }
@@ -821,7 +870,7 @@ convgemm_kernel(const ConvGemmArgs p) {
             dst[k] = u32x4{v.x, v.y, v.z, v.w};
         }
     };
-    if constexpr (FUSE2) { if (full) r_fetch_full(0); else r_fetch(0, rpre); }
+    if constexpr (FUSE2 && !LEAN_REGS) { if (full) r_fetch_full(0); else r_fetch(0, rpre); }
 
     // ---- fused second contraction (k = 1): h = snake(acc + bias) -> LDS -> acc = h . W2^T -------------------------
     if constexpr (FUSE2 && WAVES_N == 1) {
@@ -835,6 +884,7 @@ convgemm_kernel(const ConvGemmArgs p) {
         const TA* __restrict__ W2 = (const TA*)p.W2;
         const bool w2_dma = (p.N % BK) == 0;
         const int nkc2 = (p.N + BK - 1) / BK;
+        if constexpr (LEAN_REGS) w2voff_late();
         auto w2_group = [&](int g0) {               // chunks g0 .. g0 + 2 -> weight buffers 0 .. 2 (the caller has made the ring free)
             for (int q = 0; q < 3 && g0 + q < nkc2; ++q) {
                 if (w2_dma) w_dma_issue(ws_lds + (unsigned)(q * WBUF), W2 + (long long)(g0 + q) * BK, w2voff);
@@ -852,11 +902,12 @@ convgemm_kernel(const ConvGemmArgs p) {
             for (int j = 0; j < WN; ++j) {
                 const int n = j * 32 + l31;
                 const bool nv = n < p.N;
-                const float ea = ia[j], eib = iib[j];           // the unit's inner activation is always SnakeBeta
+                // the unit's inner activation is always SnakeBeta
+                const float ea = INNER_LDS ? inn_lds[n] : ia[j], eib = INNER_LDS ? inn_lds[BN + n] : iib[j], ib = INNER_LDS ? inn_lds[2 * BN + n] : ibias[j];
                 unsigned char* hcol = Hw + (size_t)(4 * half) * HLD + n * sizeof(TA);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float v = q3_snake<TA>(acc[i][j][r] + ibias[j], ea, eib);
+                    const float v = q3_snake<TA>(acc[i][j][r] + ib, ea, eib);
                     if (nv) *(TA*)(hcol + ((r & 3) + 8 * (r >> 2)) * HLD) = q3_from_f32<TA>(v);
                     acc[i][j][r] = 0.f;
                 }
@@ -991,8 +1042,8 @@ convgemm_kernel(const ConvGemmArgs p) {
     constexpr int FOLD_KS = SCOLS / 32;
     const bool fold = FOLD_OK && p.W3 != nullptr;
     float* __restrict__ Pb = (FOLD_OK && p.P) ? p.P + (long long)b * p.p_batch_stride : nullptr;
-    bf16x8 w3f[FOLD_OK ? FOLD_KS : 1];
-    if constexpr (FOLD_OK) {
+    bf16x8 w3f[(FOLD_OK && !LEAN_REGS) ? FOLD_KS : 1];
+    if constexpr (FOLD_OK && !LEAN_REGS) {
         if (fold) {
 #pragma unroll
             for (int ks = 0; ks < FOLD_KS; ++ks)
@@ -1009,7 +1060,10 @@ convgemm_kernel(const ConvGemmArgs p) {
                 bf16x8 z;
                 z[0] = (bf16)t0.x; z[1] = (bf16)t0.y; z[2] = (bf16)t0.z; z[3] = (bf16)t0.w;
                 z[4] = (bf16)t1.x; z[5] = (bf16)t1.y; z[6] = (bf16)t1.z; z[7] = (bf16)t1.w;
-                pacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3f[ks], z, pacc, 0, 0, 0);
+                bf16x8 taps_ks;
+                if constexpr (LEAN_REGS) taps_ks = *(const bf16x8*)((const bf16*)p.W3 + (size_t)(lane & 15) * p.N + 32 * ks + 8 * (lane >> 4));   // 3 KB, L1 / L2 resident
+                else taps_ks = w3f[ks];
+                pacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(taps_ks, z, pacc, 0, 0, 0);
             }
             if (lane < 32 && row_ok) *(f32x4*)(Pb + (long long)(mrow0 + (lane & 15)) * 8 + 4 * (lane >> 4)) = pacc;
         }
@@ -1022,7 +1076,8 @@ convgemm_kernel(const ConvGemmArgs p) {
         constexpr bool DUAL = decltype(dual_tag)::value;
         constexpr bool FOLD = decltype(fold_tag)::value;
         constexpr bool LATE = decltype(late_tag)::value;
-        if (!FUSE2 && has_res) r_fetch_full(0);
+        // (the lean-register shapes request nothing before the epilogue: their first rows are asked for here)
+        if ((!FUSE2 || LEAN_REGS) && has_res && !LATE) r_fetch_full(0);
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
 #pragma unroll
@@ -1031,9 +1086,12 @@ convgemm_kernel(const ConvGemmArgs p) {
                 for (int rh = 0; rh < 2; ++rh) {
                     const int pidx = (i * (WN / JG) + jg / JG) * 2 + rh;
                     const int mrow0 = m0 + wm * 32 * WM + i * 32 + rh * 16, ncol0 = n0 + wn * 32 * WN + jg * 32;
-                    u32x4* const rcur = (LATE && (pidx & 1)) ? rpre2 : rpre;
+                    u32x4* const rcur = (LATE && !LEAN_REGS && (pidx & 1)) ? rpre2 : rpre;
                     if constexpr (LATE) {
-                        if (pidx + 1 < NPASS) r_fetch_into(pidx + 1, (pidx & 1) ? rpre : rpre2);
+                        // one register set (lean-register shapes): the rows of pass p are requested at its start and used at
+                        // its end, under its own column-wise phase; two sets: a whole pass ahead
+                        if constexpr (LEAN_REGS) r_fetch_into(pidx, rpre);
+                        else if (pidx + 1 < NPASS) r_fetch_into(pidx + 1, (pidx & 1) ? rpre : rpre2);
                     }
                     if (has_res && !LATE) {
                         // since the request: this tile's earlier work and waits (first pass) or one pass's stores
@@ -1095,7 +1153,8 @@ convgemm_kernel(const ConvGemmArgs p) {
                     if constexpr (FOLD) fold_pass(mrow0, true);
                     if constexpr (LATE) {
                         // rows of this pass: requested a pass ago; issued since: the last pass's stores and the next pass's request
-                        if (pidx == 0) wait_vmcnt_c<(NPASS > 1 ? NPIECE : 0)>();
+                        if constexpr (LEAN_REGS) wait_vmcnt_c<0>();          // nothing was issued since this pass's request
+                        else if (pidx == 0) wait_vmcnt_c<(NPASS > 1 ? NPIECE : 0)>();
                         else if (pidx + 1 < NPASS) wait_vmcnt_c<2 * NPIECE>();
                         else wait_vmcnt_c<NPIECE>();
                         r_pin_buf(rcur);
@@ -1104,7 +1163,7 @@ convgemm_kernel(const ConvGemmArgs p) {
                     for (int k = 0; k < (FOLD ? 0 : NPIECE); ++k) {
                         const int id = lane + 64 * k;
                         const int row = id / CPRW_F, ch = id - row * CPRW_F;
-                        const long long yo = (long long)(mrow0 + row) * p.ldy + ncol0 + ch * EPO;
+                        const long long yo = (long long)(mrow0 + row + late0) * p.ldy + ncol0 + ch * EPO;
 #pragma unroll
                         for (int which = 0; which < (DUAL ? 2 : 1); ++which) {
                             const float* sp = (which ? slabB : slabA) + row * SLD + ch * EPO;
@@ -1137,11 +1196,16 @@ convgemm_kernel(const ConvGemmArgs p) {
         if constexpr (FUSE2) {
             if (!Y2b && !has_post && !(p.debug & 128)) { fast_epilogue(std::false_type{}, std::false_type{}, std::true_type{}); mark(5); return; }
         }
-        if (Y2b) fast_epilogue(std::true_type{}, std::false_type{}, std::false_type{});
-        else fast_epilogue(std::false_type{}, std::false_type{}, std::false_type{});
-        mark(5);
-        return;
+        // (the lean-register fused shapes are launched for those two forms only - one raw output, or the folded final conv:
+        // the launcher refuses anything else - so they carry no other branch-free epilogue)
+        if constexpr (!(FUSE2 && LEAN_REGS)) {
+            if (Y2b) fast_epilogue(std::true_type{}, std::false_type{}, std::false_type{});
+            else fast_epilogue(std::false_type{}, std::false_type{}, std::false_type{});
+            mark(5);
+            return;
+        }
     }
+    if constexpr (FUSE2 && LEAN_REGS) r_fetch(0, rpre);     // partial tiles: the first pass's rows (the other shapes asked for them earlier)
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
 #pragma unroll
@@ -1324,6 +1388,8 @@ hipError_t launch_cfg(const ConvGemmArgs& a_in, hipStream_t s) {
     const int xi_total = (HR * CPR + NTHR - 1) / NTHR;
     const int xps = (xi_total + a.taps - 1) / a.taps;
     if (xps > (BM * CPR + NTHR - 1) / NTHR || xps > 4) return hipErrorInvalidValue;      // halo too large for the staged-slice scheme
+    // the twelve-wave shape: one raw output (no consumer's SnakeBeta), or the folded final conv
+    if (FUSE2 && NW == 12 && (a.Y2 || (a.post_a && !a.W3))) return hipErrorInvalidValue;
     if (a.W3 && !(FUSE2 && sizeof(TA) == 2 && WAVES_N == 1 && WN == JG && a.P && a.post_a && !a.Y2 && a.seg_len == 0 && a.N % 32 == 0 && a.N == BN))
         return hipErrorInvalidValue;
     if (FUSE2 && (a.post_elu || a.N > BN || a.K != a.N || !a.W2 || a.act != Q3_ACT_SNAKE || !a.epi_a || !a.epi_invb || !a.pre_a || !a.pre_invb || !a.R ||
@@ -1358,13 +1424,16 @@ hipError_t launch_cfg(const ConvGemmArgs& a_in, hipStream_t s) {
     // ring when one column of waves covers every channel
     if (FUSE2) lds = std::max(lds, WAVES_N == 1 ? 3 * wbuf + round_kb((size_t)NW * 32 * (BN * sizeof(TA) + 16)) + 1024
                                                 : 2 * wbuf + round_kb((size_t)BM * (BN * sizeof(TA) + 16)) + 1024);
-    if (FUSE2) lds += round_kb((size_t)2 * a.K * sizeof(float));       // the input SnakeBeta's parameters, behind the spare KiB
+    // the input SnakeBeta's parameters, behind the spare KiB; the twelve-wave shape also keeps the inner activation's [3][BN] there
+    if (FUSE2) lds += round_kb((size_t)(2 * a.K + (NW == 12 ? 3 * BN : 0)) * sizeof(float));
     lds = std::max(lds, (size_t)NW * 2 * 16 * (32 * JG + 4) * sizeof(float));    // two wave-private 16-row epilogue slabs per wave
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const bool seg = a.seg_len > 0;
     if (a.row_start && !seg) return hipErrorInvalidValue;
-    auto kern = seg ? convgemm_kernel<TA, TO, WAVES_M, WAVES_N, WM, WN, BKB, FUSE2, true>
-                    : convgemm_kernel<TA, TO, WAVES_M, WAVES_N, WM, WN, BKB, FUSE2, false>;
+    constexpr bool SEG_OK = NW != 12;        // the twelve-wave shape serves the bulk decode only (pick_shape never chooses it for segmented rows)
+    if (seg && !SEG_OK) return hipErrorInvalidValue;
+    auto kern = (seg && SEG_OK) ? convgemm_kernel<TA, TO, WAVES_M, WAVES_N, WM, WN, BKB, FUSE2, SEG_OK>
+                                : convgemm_kernel<TA, TO, WAVES_M, WAVES_N, WM, WN, BKB, FUSE2, false>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -1378,7 +1447,7 @@ hipError_t launch_cfg(const ConvGemmArgs& a_in, hipStream_t s) {
 
 // tile shapes (rows x columns, K-row bytes, waves)
 enum { SH_256x96 = 0, SH_256x128_K128, SH_128x128_K128, SH_128x128_K64, SH_256x32, SH_F_256x192, SH_F_256x96, SH_F_256x32,
-       SH_256x128_K64, SH_F_128x192, SH_F_128x384, SH_256x64, SH_128x32_K128, SH_128x64_K128, SH_COUNT };
+       SH_256x128_K64, SH_F_128x192, SH_F_128x384, SH_256x64, SH_128x32_K128, SH_128x64_K128, SH_F_768x96, SH_COUNT };
 
 int pick_shape(const ConvGemmArgs& a, size_t elem) {
     // rows that decide the shape: a launch that computes only the tail of its rows keeps the whole tensor's shape (the shape
@@ -1386,6 +1455,14 @@ int pick_shape(const ConvGemmArgs& a, size_t elem) {
     const long long rows_all = (long long)a.B * (a.shape_rows > 0 ? a.shape_rows : a.M);
     if (a.W2) {                                   // fused residual unit: one N tile must hold every channel
         if (a.N <= 32) return SH_F_256x32;
+        // 33-96 channels in bf16 over at least four rounds of tiles: 768-row tiles on TWELVE waves (64 rows x 96 columns each, as in
+        // the four-wave shape, so the sums come out bit for bit the same), 150 KB of LDS, one block per CU = three waves per SIMD
+        // at 168 registers: 3-4 % faster than two four-wave blocks per CU (tuning bit 1 << 22 keeps the four-wave shape).
+        // Measured and dropped on the way: 384-row tiles on six waves (two blocks per CU would fit by LDS and registers, but a
+        // six-wave block takes two wave slots on every SIMD when it is placed, so only ONE block is ever resident: 550 against
+        // 665 TFLOP/s) and 128-row tiles on four waves, three blocks per CU (650 against 680).
+        if (a.N <= 96 && a.N > 32 && elem == 2 && a.seg_len == 0 && a.N % 32 == 0 && rows_all >= 768LL * 1024 && !a.Y2 && (!a.post_a || a.W3) &&
+            !(a.tuning & (1 << 22))) return SH_F_768x96;
         if (a.N <= 96) return SH_F_256x96;       // (128-row tiles, three blocks per CU: measured 9 % slower)
         // 128-row tiles on four waves keep the unit's LDS under 80 KB: two independent blocks per CU, one's h tile and
         // epilogue under the other's MFMAs, against one 8-wave block in lockstep
@@ -1452,6 +1529,9 @@ hipError_t launch_typed(const ConvGemmArgs& a, hipStream_t s) {
             case SH_F_128x384:
                 if constexpr (sizeof(TA) == 2) return launch_cfg<TA, TO, 2, 4, 2, 3, 64, true>(a, s);
                 break;
+            case SH_F_768x96:
+                if constexpr (sizeof(TA) == 2 && sizeof(TO) == 2) return launch_cfg<TA, TO, 12, 1, 2, 3, 64, true>(a, s);
+                else return launch_cfg<TA, TO, 4, 1, 2, 3, 64, true>(a, s);
             case SH_F_256x96: return launch_cfg<TA, TO, 4, 1, 2, 3, 64, true>(a, s);
             case SH_F_256x32: return launch_cfg<TA, TO, 4, 1, 2, 1, 64, true>(a, s);
             default: break;

@@ -486,6 +486,62 @@ def test_one_launch_unit_at_384_channels_matches_two_launches():
         assert max_abs(want, got) <= BF16_CHAIN_REL * max(top, 1.0), (tag, max_abs(want, got), top)
 
 
+TWELVE_WAVE_OFF = 1 << 22      # the library's measurement knob: keep four-wave 256-row tiles for the 96-channel unit
+
+
+@pytest.mark.parametrize("dilation", [1, 9])
+def test_twelve_wave_unit_is_bit_identical_to_the_four_wave_unit(dilation):
+    """The 96-channel bf16 unit over >= 786 432 rows takes 768-row tiles on twelve waves (the bulk decode's last block); fewer
+    rows, or the knob, take four-wave 256-row tiles.  Same per-wave tile, same summation order: bit-identical outputs, for items
+    whose rows do not fill the last tile; and within the bf16 chain tolerance of the oracle on one item."""
+    from qwen3_tts_amd import decoder as D, _lib
+    g = torch.Generator().manual_seed(17 + dilation)
+    rnd = lambda *shape, s=1.0: torch.randn(*shape, generator=g) * s
+    C, B, L = 96, 4, 197000 + 37
+    w = {"ru.act1.alpha": rnd(C, s=0.3), "ru.act1.beta": rnd(C, s=0.3), "ru.conv1.conv.weight": rnd(C, C, 7, s=(7 * C) ** -0.5),
+         "ru.conv1.conv.bias": rnd(C, s=0.1), "ru.act2.alpha": rnd(C, s=0.3), "ru.act2.beta": rnd(C, s=0.3),
+         "ru.conv2.conv.weight": rnd(C, C, 1, s=0.5 * C ** -0.5), "ru.conv2.conv.bias": rnd(C, s=0.1)}
+    x = rnd(B, C, L)
+    xd = x.permute(0, 2, 1).contiguous().cuda()
+    twelve = D.residual_unit(xd, w, "ru.", dilation, precision="bf16")
+    lib = _lib.load()
+    lib.q3c_debug_set_operator_context(TWELVE_WAVE_OFF, None, 0)
+    try:
+        four = D.residual_unit(xd, w, "ru.", dilation, precision="bf16")
+    finally:
+        lib.q3c_debug_set_operator_context(0, None, 0)
+    assert torch.equal(twelve, four)
+    want = oracle.residual_unit(x[:1], w, "ru.", dilation).permute(0, 2, 1).numpy()
+    top = float(np.abs(want).max())
+    assert max_abs(want, twelve[:1].cpu().numpy()) <= BF16_CHAIN_REL * max(top, 1.0)
+
+
+def test_twelve_wave_unit_in_the_bulk_decode_is_bit_identical():
+    """Flagship widths, 4 x 110 frames = 844 800 rows in the last block: its three units run twelve-wave tiles, the last one with
+    the final conv folded into its epilogue.  The waveform equals, bit for bit, the one the four-wave tiles produce."""
+    from qwen3_tts_amd.decoder import Decoder
+    cfg = q3.flagship_config()
+    dec = Decoder(cfg, q3.synthetic_weights(cfg, 0, profile="conditioned"), precision="bf16")
+    codes = q3.random_codes(cfg, 4, 110, seed=3).cuda()
+    dec.profile(True, detail=True)
+    a = dec.forward(codes)
+    torch.cuda.synchronize()
+    names = [p_["kernel"] for p_ in dec.profile_read()]
+    dec.profile(False)
+    dec.set_tuning(TWELVE_WAVE_OFF)
+    try:
+        dec.profile(True, detail=True)               # counts start again
+        b = dec.forward(codes)
+        torch.cuda.synchronize()
+        names_off = [p_["kernel"] for p_ in dec.profile_read()]
+    finally:
+        dec.set_tuning(0)
+        dec.profile(False)
+    assert any("resunit 768x96" in n for n in names), names
+    assert not any("resunit 768x96" in n for n in names_off) and any("resunit 256x96" in n for n in names_off), names_off
+    assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
+
+
 
 @pytest.mark.parametrize("precision", ["f32", "bf16"])
 def test_depthwise_conv_layernorm_row_walking_kernel_equals_the_per_row_kernel(precision):
