@@ -121,7 +121,9 @@ int q3c_forward_scatter(q3c_ctx* ctx, const int64_t* codes_dev, int32_t batch, i
  * until the process ends; its address on the context's device is looked up once, in q3c_finalize), and the call neither
  * allocates nor frees device memory.  Inputs and outputs are still the caller's.  A batch x frames whose
  * q3c_workspace_bytes exceeds Q3C_STATIC_SCRATCH_BYTES is refused with Q3C_ERR_WORKSPACE; per-kernel profiling must be off
- * (Q3C_ERR_STATE).  Nothing in the workspace needs to start at zero - every region is written before it is read - so the
+ * (Q3C_ERR_STATE).  HOW MUCH FITS: the workspace grows by about 1.5 MB per frame of the batch at the production widths in bf16
+ * (four arenas of frames x 1920 rows x 96 channels), so 64 MiB hold ABOUT 40 FRAMES IN ALL (3.2 s of audio: one call of
+ * batch 1 x 40 frames, or 4 x 10) - a low-latency first chunk, not a bulk decode; ask q3c_workspace_bytes before relying on a shape.  Nothing in the workspace needs to start at zero - every region is written before it is read - so the
  * previous call's contents are simply overwritten; but all contexts on one GPU share the one array: calls that overlap in
  * time on the same GPU (two streams, two contexts, two threads) race and must be serialised by the caller. */
 #define Q3C_STATIC_SCRATCH_BYTES (64u << 20)

@@ -48,9 +48,15 @@ class DecodeBatcher:
         if self._closed:
             raise RuntimeError("DecodeBatcher is closed")
         items = self._dec._normalize_items(encoded)
+        bins = getattr(getattr(self._dec, "cfg", None), "codebook_size", None)
         for c in items:
             if int(c.shape[1]) < 1:
                 raise ValueError("empty code sequence")
+            # codes that live on the host are range-checked here (as torch's embedding would raise in a direct call): a bad
+            # request then fails alone and at once, instead of failing its whole window on the device and making every
+            # neighbour decode a second time.  Device tensors are left to the device-side check (no synchronisation here).
+            if bins is not None and not c.is_cuda and c.numel() and (int(c.min()) < 0 or int(c.max()) >= bins):
+                raise IndexError(f"code out of range [0, {bins})")
         fut: Future = Future()
         self._q.put((items, fut))
         return fut

@@ -608,6 +608,7 @@ class StreamPool:
         self._ws: Optional[torch.Tensor] = None
         self._free = list(range(self.capacity - 1, -1, -1))
         self._frames: Dict[int, int] = {}            # open slot -> frames pushed so far
+        self._ids_dev: Dict[tuple, torch.Tensor] = {}    # id tuples already on the device (a stable set of streams pushes again and again)
         with torch.cuda.device(decoder.device):
             decoder._check(self._lib.q3c_stream_pool_create(decoder._ctx, self.capacity, C.byref(self._pool)))
 
@@ -654,6 +655,17 @@ class StreamPool:
     def frames_pushed(self, sid: int) -> int:
         return self._frames[sid]
 
+    def _device_ids(self, ids: tuple) -> torch.Tensor:
+        """int32 device tensor of a tuple of stream ids; the 32 most recently used tuples stay on the device, so a set of
+        streams that pushes tick after tick pays the (blocking, pageable) upload once."""
+        dev = self._ids_dev.pop(ids, None)
+        if dev is None:
+            dev = torch.tensor(ids, dtype=torch.int32, device=self.dec.device)
+            while len(self._ids_dev) >= 32:
+                self._ids_dev.pop(next(iter(self._ids_dev)))
+        self._ids_dev[ids] = dev                     # (re)inserted last: dicts keep insertion order
+        return dev
+
     def push_raw(self, ids_dev: torch.Tensor, codes: torch.Tensor, out: Optional[torch.Tensor] = None, graph: bool = False) -> torch.Tensor:
         """The launch sequence alone: ids_dev int32 [S] and codes int64 [S, Q, n] on the device -> [S, n*1920] float32
         (a stream's first push starts with 555 blank samples).  No host bookkeeping and no synchronisation.
@@ -692,8 +704,7 @@ class StreamPool:
                 raise KeyError(f"stream {i} is not open")
             if self._frames[i] + n > dec.max_positions:
                 raise ValueError(f"stream {i} would exceed max_positions = {dec.max_positions} frames")
-        ids_dev = torch.tensor(ids, dtype=torch.int32, device=dec.device)
-        wav = self.push_raw(ids_dev, codes)
+        wav = self.push_raw(self._device_ids(tuple(ids)), codes)
         if check:
             with torch.cuda.device(dec.device):
                 dec._check(self._lib.q3c_check_errors(dec._ctx, dec._stream()))

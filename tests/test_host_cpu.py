@@ -507,9 +507,11 @@ def test_torch_ops_are_registered_with_shape_functions():
 class _CountingDecoder:
     """`Decoder.decode`'s contract without a GPU: waveform i = per-frame sum of utterance i's codes."""
 
-    def __init__(self, cfg):
+    def __init__(self, cfg, expose_cfg=True):
         from qwen3_tts_amd.decoder import Decoder
-        self.cfg = cfg
+        self._cfg = cfg
+        import types                                 # without the code-book size the batcher cannot range-check at submit()
+        self.cfg = cfg if expose_cfg else types.SimpleNamespace(num_quantizers=cfg.num_quantizers)
         self.calls = []
         self._norm = Decoder._normalize_items
 
@@ -520,7 +522,7 @@ class _CountingDecoder:
         items = self._normalize_items(encoded)
         self.calls.append(len(items))
         for c in items:
-            if int(c.max()) >= self.cfg.codebook_size:
+            if int(c.max()) >= self._cfg.codebook_size:
                 raise IndexError("code out of range")
         return [c.float().sum(0).numpy() for c in items], 24000
 
@@ -552,13 +554,25 @@ def test_batcher_groups_concurrent_requests_and_returns_each_its_own():
 def test_batcher_errors_stay_with_their_request():
     from qwen3_tts_amd.batcher import DecodeBatcher
     cfg = q3.tiny_config()
-    dec = _CountingDecoder(cfg)
     good = q3.random_codes(cfg, 1, 5, seed=1)[0]
     bad = good.clone()
-    bad[0, 2] = cfg.codebook_size                                   # found only by the decode itself
+    bad[0, 2] = cfg.codebook_size
+    # codes on the host are range-checked in the caller's thread: the bad request never reaches a window
+    dec = _CountingDecoder(cfg)
     with DecodeBatcher(dec, max_wait_ms=100.0) as bat:
         with pytest.raises(ValueError):                             # wrong code-book count: rejected in the caller's thread
             bat.submit(torch.zeros((cfg.num_quantizers + 1, cfg.num_quantizers + 5), dtype=torch.int64))
+        with pytest.raises(IndexError):
+            bat.submit(bad)
+        neg = good.clone()
+        neg[1, 0] = -1
+        with pytest.raises(IndexError):
+            bat.submit([good, neg])
+        assert np.array_equal(bat.decode(good)[0][0], good.float().sum(0).numpy())
+        assert dec.calls == [1]                                     # nothing was decoded twice
+    # an error found only by the decode itself (as for codes that live on the device) stays with its request
+    dec = _CountingDecoder(cfg, expose_cfg=False)
+    with DecodeBatcher(dec, max_wait_ms=100.0) as bat:
         f1, f2, f3 = bat.submit(good), bat.submit(bad), bat.submit([good, good])
         assert np.array_equal(f1.result()[0][0], good.float().sum(0).numpy())
         with pytest.raises(IndexError):
