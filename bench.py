@@ -383,7 +383,7 @@ def main() -> None:
     ap.add_argument("--push-frames", type=int, default=1)
     ap.add_argument("--sweep", default="", help="stream workload: comma-separated stream counts to measure in one run, e.g. 256,1024,4096")
     ap.add_argument("--no-graph", action="store_true", help="stream workload: plain launches instead of the HIP-graph replay")
-    ap.add_argument("--no-stream-record", action="store_true", help="skip the short streaming-latency record appended to the bulk line")
+    ap.add_argument("--no-stream-record", action="store_true", help="skip the short records of the other configurations (streaming, mixed lengths, long form) appended to the bulk line")
     ap.add_argument("--launch-check", action="store_true", help="every rank prints its rank / world size and exits (no GPU work)")
     args = ap.parse_args()
 
@@ -567,6 +567,20 @@ def main() -> None:
             sb = stream_bench(sargs, cfg, weights, device)
             out["streaming"] = {"streams": args.streams, "frames_per_push": args.push_frames, "pushes": 1000, "warmup": 50,
                                 "p50_ms": sb["config"]["p50_ms"], "p99_ms": sb["config"]["p99_ms"], "audio_sec_per_sec": sb["value"]}
+            # short records of BASELINE.json configs[3] and configs[4] as well (same process, after and outside the timed region;
+            # `--workload mixed` / `--workload longform` are the full measurements): 2 000 mixed-length utterances end to end
+            # including the copy to the host, and one 10-minute utterance chunked 300 + 25
+            del dec
+            torch.cuda.empty_cache()
+            margs = argparse.Namespace(**{**vars(args), "utterances": 2000})
+            mb = mixed_bench(margs, cfg, weights, device, 1, 0, False)
+            out["mixed_lengths"] = {"utterances": 2000, "audio_seconds": mb["config"]["audio_seconds"], "ms": mb["ms_per_step"],
+                                    "audio_sec_per_sec": mb["value"], "includes": "bucketing, launches, copy of every waveform to host memory"}
+            torch.cuda.empty_cache()
+            largs = argparse.Namespace(**{**vars(args), "seconds": 600.0, "steps": 3, "warmup": 1})
+            lb = longform_bench(largs, cfg, weights, device, 1, 0, False)
+            out["long_form"] = {"seconds": 600.0, "steps": 3, "warmup": 1, "ms_per_step": lb["ms_per_step"], "audio_sec_per_sec": lb["value"],
+                                "exact_streaming_ms": lb["config"].get("exact_streaming_ms")}
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
