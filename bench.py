@@ -406,7 +406,7 @@ def main() -> None:
     cfg = q3.tiny_config() if args.tiny else q3.flagship_config()
     weights = q3.synthetic_weights(cfg, seed=0)
     if args.workload == "stream":
-        # 50 warm-up + 1000 timed pushes unless the command line says otherwise
+        # the streaming protocol: 50 warm-up + 1000 timed pushes unless the command line says otherwise
         if "--steps" not in sys.argv:
             args.steps = 1000
         if "--warmup" not in sys.argv:

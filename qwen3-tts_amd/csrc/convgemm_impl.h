@@ -403,7 +403,7 @@ convgemm_kernel(const ConvGemmArgs p) {
     // registers: the inner activation's parameters wait in LDS ([BN] frequencies, [BN] gains, [BN] biases behind the input
     // SnakeBeta's, zeros past N; an LDS read involves no vmcnt), residual rows are requested one pass later, and the folded
     // final conv reads its taps per pass.
-    constexpr bool LEAN_REGS = waves_per_simd<TA, TO, NW, WM, WN, BKB, FUSE2>() == 3;
+    constexpr bool LEAN_REGS = FUSE2 && waves_per_simd<TA, TO, NW, WM, WN, BKB, FUSE2>() == 3;
     constexpr bool INNER_LDS = FUSE2 && WAVES_N == 1 && LEAN_REGS;
     float* inn_lds = pre_lds + 2 * p.K;
     float ia[WN], iib[WN], ibias[WN];                           // the fused unit's inner bias and SnakeBeta
