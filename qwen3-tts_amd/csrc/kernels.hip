@@ -918,7 +918,7 @@ __global__ void __launch_bounds__(256) swa_attention_mfma_kernel(const bf16* __r
 // D > 0: the head size as a compile-time constant (the loops over a row's pieces unroll, so a key's eight 16-byte pieces and
 // its rotation's table rows are all requested before the first product); D = 0: any head size.
 template <typename T, int D>
-__global__ void __launch_bounds__(256) swa_attention_step_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) swa_attention_step_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                                  const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                                  int nh, int nkv, int d, int window, float scale, int hist,
                                                                  const int* __restrict__ pos0, int max_pos, Q3KvRing ring) {
@@ -943,6 +943,34 @@ __global__ void __launch_bounds__(256) swa_attention_step_kernel(const T* __rest
     const int tld = half + 1;
     float* Cs = (float*)smem_att + (size_t)4 * (d + 64 * ATT_MAXC);
     float* Ss = Cs + (size_t)window * tld;
+    constexpr int EPV = 16 / (int)sizeof(T);
+    // Scores, known head size whose half row is a power-of-two number of 16-byte pieces (64 in bf16: 4, in fp32: 8): LPK lanes
+    // share a key - lane (g, piece) reads piece `piece` of the key's lower and upper half (the rotation pairs element e with
+    // e + half), so one load instruction covers 64 / LPK keys in whole 64- or 128-byte runs instead of 16 bytes of 64 different
+    // rows.  Five rounds of loads (40 registers) are in flight at a time: 80 keys in bf16, one pass for the decoder's 72-frame
+    // window - and the first pass is requested HERE, before the tables are staged, with the query's own elements: neither
+    // depends on the tables, so the keys' round trip to memory runs under the staging and its barrier.
+    constexpr int NPH = D > 0 ? (D / 2) / EPV : 0;             // 16-byte pieces per half row
+    constexpr bool GROUPED = D > 0 && D <= 128 && (D / 2) % EPV == 0 && NPH >= 1 && NPH <= 32 && (NPH & (NPH - 1)) == 0;
+    constexpr int LPK = GROUPED ? NPH : 1, KPI = 64 / LPK, BATCH = 5;
+    const int kg = lane / LPK, kpiece = lane - kg * LPK, ke0 = kpiece * EPV;
+    uint4 klo[BATCH], khi[BATCH];
+    auto load_keys = [&](int j0) {
+#pragma unroll
+        for (int it = 0; it < BATCH; ++it) {
+            const int jj = j0 + it * KPI + kg, j = jlo + jj;
+            if (j0 + it * KPI < cnt) {                           // wave-uniform
+                const T* kr = (jj >= cnt || j == p) ? qrow + (nh + hk) * d : ring_base + (size_t)(j % hist) * (2 * nkv * d) + hk * d;
+                klo[it] = *(const uint4*)(kr + ke0);
+                khi[it] = *(const uint4*)(kr + ke0 + half);
+            }
+        }
+    };
+    float qx1 = 0.f, qx2 = 0.f;
+    if constexpr (GROUPED) {
+        load_keys(0);
+        if (live && lane < half) { qx1 = q3_to_f32(qrow[h * d + lane]); qx2 = q3_to_f32(qrow[h * d + lane + half]); }
+    }
     if (half % 4 == 0) {
         const int q4 = half >> 2;
         for (int i = tid; i < cnt * q4; i += 256) {
@@ -967,17 +995,60 @@ __global__ void __launch_bounds__(256) swa_attention_step_kernel(const T* __rest
     {
         const float* cq = Cs + (cnt - 1) * tld;
         const float* sq = Ss + (cnt - 1) * tld;
-        for (int e = lane; e < half; e += 64) {
-            const float x1 = q3_to_f32(qrow[h * d + e]), x2 = q3_to_f32(qrow[h * d + e + half]);
-            const float c = cq[e], sn = sq[e];
-            Qs[e] = x1 * c - x2 * sn;
-            Qs[e + half] = x2 * c + x1 * sn;
+        if constexpr (GROUPED) {                               // half <= 64: one element pair per lane, loaded above
+            if (lane < half) {
+                const float c = cq[lane], sn = sq[lane];
+                Qs[lane] = qx1 * c - qx2 * sn;
+                Qs[lane + half] = qx2 * c + qx1 * sn;
+            }
+        } else {
+            for (int e = lane; e < half; e += 64) {
+                const float x1 = q3_to_f32(qrow[h * d + e]), x2 = q3_to_f32(qrow[h * d + e + half]);
+                const float c = cq[e], sn = sq[e];
+                Qs[e] = x1 * c - x2 * sn;
+                Qs[e + half] = x2 * c + x1 * sn;
+            }
         }
     }
     __builtin_amdgcn_wave_barrier();
-    constexpr int EPV = 16 / (int)sizeof(T);
     float sc[ATT_MAXC];
     float mx = -INFINITY;
+    if constexpr (GROUPED) {
+        float qlo[EPV], qhi[EPV];
+#pragma unroll
+        for (int u = 0; u < EPV; ++u) { qlo[u] = Qs[ke0 + u]; qhi[u] = Qs[ke0 + u + half]; }
+        for (int j0 = 0; j0 < cnt; j0 += BATCH * KPI) {
+            if (j0 > 0) load_keys(j0);
+#pragma unroll
+            for (int it = 0; it < BATCH; ++it) {
+                if (j0 + it * KPI < cnt) {
+                    const int jj = j0 + it * KPI + kg;
+                    const bool ok = jj < cnt;
+                    const float* cr = Cs + (ok ? jj : 0) * tld + ke0;
+                    const float* sr = Ss + (ok ? jj : 0) * tld + ke0;
+                    float alo = 0.f, ahi = 0.f;
+#pragma unroll
+                    for (int u = 0; u < EPV; ++u) {
+                        const float x1 = q3_to_f32(((const T*)&klo[it])[u]), x2 = q3_to_f32(((const T*)&khi[it])[u]);
+                        const float cc = cr[u], ss = sr[u];
+                        alo = fmaf(qlo[u], x1 * cc - x2 * ss, alo);
+                        ahi = fmaf(qhi[u], x2 * cc + x1 * ss, ahi);
+                    }
+                    float part = alo + ahi;
+#pragma unroll
+                    for (int off = 1; off < LPK; off <<= 1) part += __shfl_xor(part, off, 64);
+                    if (kpiece == 0 && ok) Ps[jj] = part * scale;          // raw score; the softmax below reads it back with lane = key
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < ATT_MAXC; ++c) {
+            sc[c] = (lane + 64 * c < cnt) ? Ps[lane + 64 * c] : -INFINITY;
+            mx = fmaxf(mx, sc[c]);
+        }
+    } else {
+
 #pragma unroll
     for (int c = 0; c < ATT_MAXC; ++c) {
         sc[c] = -INFINITY;
@@ -1010,6 +1081,27 @@ __global__ void __launch_bounds__(256) swa_attention_step_kernel(const T* __rest
         }
         mx = fmaxf(mx, sc[c]);
     }
+    }
+    // P.V, known head size: the first eight rounds of value loads do not depend on the probabilities - requested before the
+    // softmax, their round trip runs under it
+    const size_t vcol = (size_t)nkv * d + hk * d;
+    constexpr int VU = 8, VNP = GROUPED ? D / EPV : 1, VNG = 64 / VNP;
+    const int vg = lane / VNP, vpiece = lane - vg * VNP;
+    const int ring0 = jlo % hist;
+    uint4 vv[VU];
+    auto load_vals = [&](int j0) {
+        const T* vnew = qrow + (size_t)(nh + nkv + hk) * d + vpiece * EPV;
+        const T* vring = ring_base + vcol + vpiece * EPV;
+#pragma unroll
+        for (int u = 0; u < VU; ++u) {
+            const int jj = j0 + u * VNG + vg;
+            const bool ok = jj < cnt;
+            int idx = ring0 + (ok ? jj : 0);
+            idx = idx >= hist ? idx - hist : idx;
+            vv[u] = *(const uint4*)((!ok || jj == cnt - 1) ? vnew : vring + (size_t)idx * (2 * nkv * d));
+        }
+    };
+    if constexpr (GROUPED) load_vals(0);
     const float m = wave_max(mx);
     float sum = 0.f;
 #pragma unroll
@@ -1024,7 +1116,31 @@ __global__ void __launch_bounds__(256) swa_attention_step_kernel(const T* __rest
     for (int c = 0; c < ATT_MAXC; ++c)
         if (64 * c < cnt) Ps[lane + 64 * c] = sc[c] * inv;
     __builtin_amdgcn_wave_barrier();
-    const size_t vcol = (size_t)nkv * d + hk * d;
+    if constexpr (GROUPED) {
+        float acc[EPV];
+#pragma unroll
+        for (int u = 0; u < EPV; ++u) acc[u] = 0.f;
+        for (int j0 = 0; j0 < cnt; j0 += VU * VNG) {
+            if (j0 > 0) load_vals(j0);
+            float pj[VU];
+#pragma unroll
+            for (int u = 0; u < VU; ++u) { const int jj = j0 + u * VNG + vg; pj[u] = jj < cnt ? Ps[jj] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < VU; ++u)
+#pragma unroll
+                for (int q = 0; q < EPV; ++q) acc[q] = fmaf(pj[u], q3_to_f32(((const T*)&vv[u])[q]), acc[q]);
+        }
+        for (int off = VNP; off < 64; off <<= 1)
+#pragma unroll
+            for (int q = 0; q < EPV; ++q) acc[q] += __shfl_xor(acc[q], off, 64);
+        if (vg == 0) {
+            uint4 o;
+#pragma unroll
+            for (int q = 0; q < EPV; ++q) ((T*)&o)[q] = q3_from_f32<T>(acc[q]);
+            *(uint4*)(out + (size_t)b * (nh * d) + h * d + vpiece * EPV) = o;
+        }
+        return;
+    }
     // P.V.  A value row is NP = d / EPV 16-byte pieces; when NP is a power of two <= 64 the wave's lanes form 64 / NP key groups
     // of NP lanes: lane (g, piece) walks keys g, g + NG, ... with ONE 16-byte load per key, eight keys' loads in flight before
     // their products are summed (a serial walk over the keys pays a memory round trip per key: 36 of them for a 72-frame
@@ -1037,7 +1153,6 @@ __global__ void __launch_bounds__(256) swa_attention_step_kernel(const T* __rest
         for (int u = 0; u < EPV; ++u) acc[u] = 0.f;
         const T* vnew = qrow + (size_t)(nh + nkv + hk) * d + piece * EPV;
         const T* vring = ring_base + vcol + piece * EPV;
-        const int ring0 = jlo % hist;
         constexpr int U = 8;
         for (int j0 = 0; j0 < cnt; j0 += U * NG) {
             uint4 v[U];
