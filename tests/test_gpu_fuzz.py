@@ -22,3 +22,12 @@ def test_random_architectures_and_plans_against_the_oracle(seed, capsys):
     for i in range(12):
         ok = fuzz.one_case(i, rng, verbose=False)
         assert ok, capsys.readouterr().out
+
+
+def test_random_encoders_and_lengths_against_the_oracle(capsys):
+    """The encode side the same way: random small encoders (strides, widths, heads, windows), batch sizes and audio lengths
+    that no stride divides - fp32 embeddings within 1e-4 of the oracle's, codes equal up to near-ties."""
+    rng = random.Random(21)
+    for i in range(16):
+        ok = fuzz.encode_case(i, rng, verbose=False)
+        assert ok, capsys.readouterr().out

@@ -3,9 +3,11 @@ lengths, chunk plans and push plans.  Every case checks, in fp32 (max-abs <= 1e-
 conditioned weight profile (SNR >= 30 dB at these small widths), the un-chunked forward, chunked_decode with a random
 (chunk, context), the ragged `decode` wrapper and a stream advanced by random push sizes.  Channel counts stay multiples
 of 8 (the library's requirement: 16-byte rows in bf16).
+`--encode N` adds N cases of the tokenizer's encode side: random small encoders (strides, widths, heads, windows), batch
+sizes and audio lengths that no stride divides; fp32 embeddings within 1e-4 of the oracle's and >= 99 % of the codes equal.
 Prints one line per case and a summary; exits 1 at the first violation.
 
-    python tools/fuzz_parity.py [--cases 60] [--seed 0]
+    python tools/fuzz_parity.py [--cases 60] [--encode 0] [--seed 0]
 """
 import argparse
 import os
@@ -99,16 +101,59 @@ def one_case(i, rng, verbose=True):
     return not fails
 
 
+def encode_case(i, rng, verbose=True):
+    import importlib
+    import encoder_oracle as eo
+    E = importlib.import_module("qwen3-tts_amd.encoder")
+    heads, head_dim = rng.choice([(2, 16), (4, 16), (2, 32), (4, 32), (2, 64)])
+    ecfg = E.EncoderConfig(num_filters=rng.choice([16, 32]), ratios=tuple(rng.choice([(2, 3), (4, 2), (3, 2, 2), (2, 2, 3), (5, 2)])),
+                           hidden_size=heads * head_dim, num_attention_heads=heads, head_dim=head_dim,
+                           intermediate_size=rng.choice([64, 128]), num_hidden_layers=rng.choice([1, 2]),
+                           sliding_window=rng.choice([3, 9, 250]))
+    cfg = q3.tiny_config("split_rvq", num_quantizers=rng.choice([2, 4, 8]), codebook_size=rng.choice([16, 64]),
+                         codebook_dim=rng.choice([8, 16]), rvq_out_dim=ecfg.hidden_size)
+    seed = rng.randint(0, 10 ** 6)
+    w = {**q3.synthetic_weights(cfg, seed=seed % 89), **E.synthetic_encoder_weights(ecfg, cfg.codebook_dim, seed=seed % 83)}
+    B, L = rng.randint(1, 3), rng.choice([rng.randint(1, ecfg.hop), rng.randint(ecfg.hop + 1, 40 * ecfg.hop), rng.randint(40 * ecfg.hop, 120 * ecfg.hop)])
+    audio = torch.randn(B, L, generator=torch.Generator().manual_seed(seed)) * 0.3
+    t0 = time.time()
+    want_codes, want_emb = eo.encode(ecfg, cfg, w, audio[:, None, :])
+    want_emb = want_emb.permute(0, 2, 1).numpy()
+    dec = Decoder(cfg, w, device="cuda:0", precision="f32", encoder=ecfg)
+    codes, emb = dec.encode(audio, return_embeddings=True)
+    fails = []
+    if tuple(codes.shape) != tuple(want_codes.shape):
+        fails.append(f"codes shape {tuple(codes.shape)} != {tuple(want_codes.shape)}")
+    else:
+        err = float(np.abs(want_emb - emb.cpu().numpy()).max())
+        agree = float((codes.cpu() == want_codes).float().mean())
+        if err > 1e-4 * max(1.0, float(np.abs(want_emb).max())):
+            fails.append(f"embeddings max|err| {err:.3e}")
+        if agree < 0.99 and codes.numel() * (1 - agree) > 2:        # a near-tie or two among a handful of frames is not a failure
+            fails.append(f"codes equal {100 * agree:.2f} %")
+    if verbose or fails:
+        print(f"encode case {i}: filters {ecfg.num_filters}, strides {ecfg.ratios}, {heads} x {head_dim}, layers {ecfg.num_hidden_layers}, "
+              f"window {ecfg.sliding_window}, Q {cfg.num_quantizers} x {cfg.codebook_size}, B {B}, L {L} ({ecfg.frames(L)} frames): "
+              f"{'ok' if not fails else 'FAIL'} ({time.time() - t0:.1f} s)", flush=True)
+    for f in fails:
+        print("   ", f, flush=True)
+    return not fails
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=60)
+    ap.add_argument("--encode", type=int, default=0)
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
     rng = random.Random(args.seed)
     for i in range(args.cases):
         if not one_case(i, rng):
             sys.exit(1)
-    print(f"{args.cases} cases ok (seed {args.seed})")
+    for i in range(args.encode):
+        if not encode_case(i, rng):
+            sys.exit(1)
+    print(f"{args.cases} decode cases and {args.encode} encode cases ok (seed {args.seed})")
 
 
 if __name__ == "__main__":
