@@ -102,6 +102,81 @@ def to_host(flat: torch.Tensor) -> np.ndarray:
     return res
 
 
+_COPY_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def to_host_by_launch(flat: torch.Tensor, total: int, ends: Sequence[int], events: Sequence["torch.cuda.Event"],
+                      p_dev: np.ndarray, p_host: np.ndarray, p_n: np.ndarray) -> np.ndarray:
+    """Device samples laid out launch by launch -> one float32 numpy array in the caller's order, WHILE the later launches
+    still run: launch k's samples end at element `ends[k]` of `flat` and are complete when `events[k]` has fired; piece i is
+    `p_n[i]` samples at device offset `p_dev[i]` (ascending) that belong at host offset `p_host[i]`.  The copies go through
+    the device's two pinned staging buffers on a stream of their own, each waiting only for the launches it covers, and
+    every staged range is scattered to its pieces' places by a few threads."""
+    import bisect
+    res = np.empty(total, dtype=np.float32)
+    n = int(flat.numel())
+    if n == 0:
+        return res
+    dev = flat.device
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    p_dev_l = p_dev.tolist()
+
+    def scatter(src: np.ndarray, a: int, b: int) -> None:
+        i = max(0, bisect.bisect_right(p_dev_l, a) - 1)
+        jobs = []
+        while i < len(p_dev_l) and p_dev_l[i] < b:
+            lo, hi = max(a, p_dev_l[i]), min(b, p_dev_l[i] + int(p_n[i]))
+            if hi > lo:
+                jobs.append((int(p_host[i]) + lo - p_dev_l[i], lo - a, hi - lo))
+            i += 1
+        if len(jobs) > 4 and b - a >= (2 << 20):
+            global _copy_pool
+            if _copy_pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                _copy_pool = ThreadPoolExecutor(max_workers=_COPY_THREADS, thread_name_prefix="q3tts-d2h")
+            per = -(-len(jobs) // _COPY_THREADS)
+
+            def part(g):
+                for h, o, c in jobs[g:g + per]:
+                    res[h:h + c] = src[o:o + c]
+            list(_copy_pool.map(part, range(0, len(jobs), per)))
+        else:
+            for h, o, c in jobs:
+                res[h:h + c] = src[o:o + c]
+
+    if n <= (1 << 20):                                      # small results: not worth the staging
+        scatter(flat.cpu().numpy(), 0, n)
+        return res
+    stage, stage_ev, lock = _stage_buffers(dev)
+    with _STAGE_GUARD:
+        if dev.index not in _COPY_STREAMS:
+            _COPY_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
+        copy_stream = _COPY_STREAMS[dev.index]
+    flat.record_stream(copy_stream)
+    piece = _STAGE_PIECE // 4
+    bounds = [(a, min(a + piece, n)) for a in range(0, n, piece)]
+    ends_l = list(ends)
+
+    def issue(k: int, j: int) -> None:
+        a, b = bounds[k]
+        copy_stream.wait_event(events[min(bisect.bisect_left(ends_l, b), len(events) - 1)])      # the launch that writes element b - 1
+        with torch.cuda.stream(copy_stream):
+            stage[j].view(torch.float32)[: b - a].copy_(flat[a:b], non_blocking=True)
+            stage_ev[j].record(copy_stream)
+
+    with lock, torch.cuda.device(dev):
+        for k in range(min(2, len(bounds))):
+            issue(k, k)
+        for k, (a, b) in enumerate(bounds):
+            j = k & 1
+            stage_ev[j].synchronize()
+            scatter(stage[j].numpy().view(np.float32), a, b)
+            if k + 2 < len(bounds):
+                issue(k + 2, j)
+    return res
+
+
 class Decoder:
     """One decoder instance = one q3c context on one GPU."""
 
@@ -441,9 +516,12 @@ class Decoder:
         return one(encoded)
 
     def decode_device(self, encoded: CodesLike, chunk_size: Optional[int] = None, left_context_size: Optional[int] = None,
-                      pad_to: Optional[int] = None) -> Tuple[torch.Tensor, List[int], List[int]]:
+                      pad_to: Optional[int] = None, _by_launch: bool = False):
         """The decode of `decode` without the copy to the host: -> (flat float32 device tensor holding every
-        utterance's samples back to back, start offset per utterance, length per utterance)."""
+        utterance's samples back to back, start offset per utterance, length per utterance).
+        `_by_launch` (used by `decode`): the device tensor holds the samples launch by launch instead - what a launch
+        produces is contiguous, so it can leave for the host while the next launches run - and a fourth value describes the
+        layout: (end offset per launch, event per launch, and per piece its device offset, host offset and length)."""
         cs = self.cfg.chunk_size if chunk_size is None else chunk_size
         lc = self.cfg.left_context_size if left_context_size is None else left_context_size
         items = self._normalize_items(encoded)
@@ -464,7 +542,8 @@ class Decoder:
                 off += self.cfg.output_length(e - s) - ctx * up
         out = torch.empty(total, dtype=torch.float32, device=self.device)
         if not items:
-            return out, starts, lengths
+            return (out, starts, lengths, ([], [], np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.int64))) if _by_launch \
+                else (out, starts, lengths)
         flat_codes, bases = None, None
         if len(items) > 1 and all(c.device.type == "cpu" for c in items):      # one copy to the device, then views
             # (a zero column at the end: the source of every padding frame when a launch's codes are gathered in one go)
@@ -496,11 +575,16 @@ class Decoder:
                 launches.append((Lb, skip, idxs[i0:i0 + per]))
         # where every piece's kept samples go: (offset into `out`, count) per launch row, one table for all launches
         span_rows, span_off = [], []
+        host_rows, launch_ends, dev_o = [], [], 0
         for Lb, _skip, sub in launches:
             span_off.append(len(span_rows))
             for j in sub:
                 i, s, e, ctx, off = jobs[j]
-                span_rows.append((starts[i] + off, self.cfg.output_length(e - s) - ctx * up))
+                cnt = self.cfg.output_length(e - s) - ctx * up
+                span_rows.append((dev_o if _by_launch else starts[i] + off, cnt))
+                host_rows.append(starts[i] + off)
+                dev_o += cnt
+            launch_ends.append(dev_o)
         spans_host = np.asarray(span_rows, dtype=np.int64).reshape(-1, 2)
         idx_dev, idx_off = None, []
         if flat_codes is not None:
@@ -521,6 +605,7 @@ class Decoder:
             idx_dev, spans_dev = both[:total_idx], both[total_idx:].view(-1, 2)
         else:
             spans_dev = torch.from_numpy(spans_host).to(self.device)
+        launch_events: List["torch.cuda.Event"] = []
         for k, (Lb, skip, sub) in enumerate(launches):
             if idx_dev is not None:
                 idx = idx_dev[idx_off[k]: idx_off[k] + len(sub) * Lb].view(len(sub), Lb)
@@ -531,6 +616,13 @@ class Decoder:
                     i, s, e, _ctx, _off = jobs[j]
                     batch[n, :, : e - s] = dev_items[i][:, s:e]
             self._forward_kept(batch, skip, spans_dev[span_off[k]: span_off[k] + len(sub)], out)
+            if _by_launch:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+                launch_events.append(ev)
+        if _by_launch:      # no error check here: it waits for the stream, and the caller's copies are meant to run under the launches
+            return out, starts, lengths, (launch_ends, launch_events, spans_host[:, 0].copy(), np.asarray(host_rows, dtype=np.int64),
+                                          spans_host[:, 1].copy())
         with torch.cuda.device(self.device):
             self._check(self._lib.q3c_check_errors(self._ctx, self._stream()))
         return out, starts, lengths
@@ -542,8 +634,13 @@ class Decoder:
         there are enough pieces to fill the finer buckets), pieces of equal padded
         length share a launch sequence, and each piece keeps only its own prefix of the output (a frame never
         influences samples that precede it by more than the fixed 555-sample lookahead)."""
-        out, starts, lengths = self.decode_device(encoded, chunk_size, left_context_size, pad_to)
-        host = self._to_host(out)
+        out, starts, lengths, (ends, events, p_dev, p_host, p_n) = self.decode_device(encoded, chunk_size, left_context_size, pad_to,
+                                                                                      _by_launch=True)
+        try:
+            host = to_host_by_launch(out, sum(lengths), ends, events, p_dev, p_host, p_n)
+        finally:            # the device-side error flag (a code outside the code book), read once everything has run
+            with torch.cuda.device(self.device):
+                self._check(self._lib.q3c_check_errors(self._ctx, self._stream()))
         return [host[s:s + n] for s, n in zip(starts, lengths)], self.cfg.sample_rate
 
     def _to_host(self, flat: torch.Tensor) -> np.ndarray:
