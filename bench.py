@@ -57,6 +57,7 @@ if __name__ == "__main__":
     if _cmd is not None:
         sys.exit(subprocess.run(_cmd).returncode)
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 import qwen3_tts_amd as q3  # noqa: E402
@@ -488,6 +489,19 @@ def main() -> None:
         host = dec._to_host(step())
     elapsed_d2h = (time.perf_counter() - t1) / psteps
     assert host.shape[0] == wav.numel()
+    # (b2) the same utterances through the wrapper the reference calls - `decode(list of code matrices) -> (list of numpy
+    # waveforms, sample rate)`: bucketing, the launches, and the copies to host memory running under the later launches
+    elapsed_wrapper = None
+    if not args.unchunked:
+        utts = [codes[b] for b in range(args.batch)]
+        dec.decode(utts)
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        for _ in range(psteps):
+            wavs_host, _sr = dec.decode(utts)
+        elapsed_wrapper = (time.perf_counter() - t1) / psteps
+        assert len(wavs_host) == args.batch and wavs_host[0].shape[0] == cfg.chunked_output_length(frames)
+        assert np.array_equal(wavs_host[0], host[: wavs_host[0].shape[0]]), "the wrapper's samples differ from chunked_decode's"
     # (c) the same step with every row of each chunk's left context computed (Decoder.skip_context off): the chunked decode as a
     # loop of whole forwards would run it.  The samples are bit for bit the same (checked here on the first utterance).
     ms_full_context = None
@@ -549,6 +563,8 @@ def main() -> None:
                        "gpu_event_ms_per_step": round(ev0.elapsed_time(ev1) / args.steps, 3),
                        "value_incl_d2h": round(args.batch * frames / cfg.frame_rate / elapsed_d2h, 1),
                        "ms_per_step_incl_d2h": round(elapsed_d2h * 1e3, 3),
+                       **({"value_decode_wrapper": round(args.batch * frames / cfg.frame_rate / elapsed_wrapper, 1),
+                           "ms_per_step_decode_wrapper": round(elapsed_wrapper * 1e3, 3)} if elapsed_wrapper else {}),
                        **({"dead_context_rows": "the conv-decoder rows under each later chunk's 25 dropped context frames are not "
                                                 "computed (q3c_forward_skip); samples bit-identical to whole forwards",
                            "ms_per_step_with_context_rows_computed": round(ms_full_context, 3)} if ms_full_context else {})},

@@ -545,9 +545,10 @@ class Decoder:
             return (out, starts, lengths, ([], [], np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.int64))) if _by_launch \
                 else (out, starts, lengths)
         flat_codes, bases = None, None
-        if len(items) > 1 and all(c.device.type == "cpu" for c in items):      # one copy to the device, then views
+        if len(items) > 1 and (all(c.device.type == "cpu" for c in items) or all(c.device == self.device for c in items)):
+            # one tensor on the device (for host codes: one copy), then views
             # (a zero column at the end: the source of every padding frame when a launch's codes are gathered in one go)
-            flat_codes = torch.cat(items + [torch.zeros((Q, 1), dtype=torch.int64)], dim=1).to(self.device)
+            flat_codes = torch.cat(list(items) + [torch.zeros((Q, 1), dtype=torch.int64, device=items[0].device)], dim=1).to(self.device)
             dev_items, bases, o = [], [], 0
             for c in items:
                 dev_items.append(flat_codes[:, o:o + int(c.shape[1])])
@@ -573,6 +574,8 @@ class Decoder:
             per = max(1, self.max_frames_per_launch // Lb)
             for i0 in range(0, len(idxs), per):
                 launches.append((Lb, skip, idxs[i0:i0 + per]))
+        # largest first: the samples of the LAST launch are the only ones whose way to the host nothing can hide
+        launches.sort(key=lambda l: -l[0] * len(l[2]))
         # where every piece's kept samples go: (offset into `out`, count) per launch row, one table for all launches
         span_rows, span_off = [], []
         host_rows, launch_ends, dev_o = [], [], 0
