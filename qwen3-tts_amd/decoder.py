@@ -117,9 +117,6 @@ def to_host_by_launch(flat: torch.Tensor, total: int, ends: Sequence[int], event
     n = int(flat.numel())
     if n == 0:
         return res
-    dev = flat.device
-    if dev.index is None:
-        dev = torch.device("cuda", torch.cuda.current_device())
     p_dev_l = p_dev.tolist()
 
     def scatter(src: np.ndarray, a: int, b: int) -> None:
@@ -148,6 +145,9 @@ def to_host_by_launch(flat: torch.Tensor, total: int, ends: Sequence[int], event
     if n <= (1 << 20):                                      # small results: not worth the staging
         scatter(flat.cpu().numpy(), 0, n)
         return res
+    dev = flat.device
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
     stage, stage_ev, lock = _stage_buffers(dev)
     with _STAGE_GUARD:
         if dev.index not in _COPY_STREAMS:

@@ -762,3 +762,26 @@ def test_server_schemas_and_request_shaping_follow_the_reference():
     src = server.hashed_code_source(cfg)
     a, b = src(text="hello", seed=1), src(text="hello", seed=1)
     assert torch.equal(a, b) and a.shape[0] == cfg.num_quantizers and not torch.equal(a, src(text="hello", seed=2))
+
+
+def test_launch_ordered_samples_reach_their_places_on_the_host():
+    """`to_host_by_launch`: a device tensor laid out launch by launch, pieces that belong at scattered host offsets.  On the
+    CPU only the small-result path runs (no staging, no streams), which shares the placement logic with the staged path."""
+    from qwen3_tts_amd.decoder import to_host_by_launch
+    rng = np.random.default_rng(3)
+    counts = rng.integers(1, 400, size=57)
+    host_order = rng.permutation(len(counts))                      # piece k of the device layout is utterance piece host_order[k]
+    host_starts = np.zeros(len(counts), dtype=np.int64)
+    o = 0
+    for k in np.argsort(host_order):                               # host layout: pieces in host order, back to back
+        host_starts[k] = o
+        o += counts[k]
+    total = int(counts.sum())
+    dev_starts = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int64)
+    want = rng.standard_normal(total).astype(np.float32)
+    flat = torch.empty(total, dtype=torch.float32)
+    for k in range(len(counts)):
+        flat[dev_starts[k]: dev_starts[k] + counts[k]] = torch.from_numpy(want[host_starts[k]: host_starts[k] + counts[k]])
+    got = to_host_by_launch(flat, total, [int(dev_starts[20]), total], [None, None], dev_starts, host_starts, counts.astype(np.int64))
+    assert np.array_equal(got, want)
+    assert to_host_by_launch(torch.empty(0), 0, [], [], np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.int64)).shape == (0,)
