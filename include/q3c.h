@@ -235,7 +235,8 @@ int q3c_profile_read(q3c_ctx* ctx, q3c_profile_entry* out, int32_t capacity, int
  * q3c_debug_set_tuning: switches that make the following launches of this context choose another tile shape or kernel than
  * the default (0).  Bits 0-7, 16-19: tile-shape choices of the contraction kernel (csrc/convgemm_impl.h); 64: the 384-channel
  * residual unit as one launch; 256: the vector-ALU attention kernel for every case; 512: the final conv as its own launch;
- * 1 << 20: the vector-ALU code-book search.  Every choice computes the same operation.
+ * 1 << 20: the vector-ALU code-book search; 1 << 22: four-wave 256-row tiles for the 96-channel residual unit where the default
+ *    is twelve-wave 768-row tiles (bit-identical results).  Every choice computes the same operation.
  * q3c_debug_set_timeline: every 64th workgroup of this context's contraction launches stores clock values at its phase
  * boundaries into dev_buffer (8 x int64 per slot); NULL switches it off. */
 int q3c_debug_set_tuning(q3c_ctx* ctx, int32_t bits);
