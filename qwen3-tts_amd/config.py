@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import dataclasses
 import math
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Dict, List, Tuple
 
 FRONTEND_SPLIT_RVQ = "split_rvq"          # Mimi-style split residual VQ + 1x1 output_proj + pre_conv

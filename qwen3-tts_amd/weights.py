@@ -17,7 +17,7 @@ from typing import Dict, List, Tuple
 
 import torch
 
-from .config import DecoderConfig, FRONTEND_MEAN_EMBEDDING, FRONTEND_SPLIT_RVQ
+from .config import DecoderConfig, FRONTEND_MEAN_EMBEDDING
 
 # kinds: how the generator draws a tensor
 _W = "weight"       # N(0, gain^2 / fan_in)

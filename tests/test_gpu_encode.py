@@ -13,7 +13,7 @@ import torch
 import qwen3_tts_amd as q3
 from qwen3_tts_amd.decoder import Decoder
 
-from gpu_util import max_abs, oracle, snr_db
+from gpu_util import max_abs, snr_db
 from test_oracle_golden import encoder_fixture
 
 import encoder_oracle as eo

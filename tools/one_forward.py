@@ -19,7 +19,6 @@ args = ap.parse_args()
 cfg = q3.flagship_config()
 dec = Decoder(cfg, q3.synthetic_weights(cfg, 0), precision=args.precision, max_frames_per_launch=args.batch * 325)
 codes = q3.random_codes(cfg, args.batch, args.frames, 1).cuda()
-from qwen3_tts_amd import _lib
 dec.set_tuning(args.tuning)
 for _ in range(1 + args.reps):
     wav = dec.forward(codes)

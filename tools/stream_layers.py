@@ -16,7 +16,6 @@ ap.add_argument("--tuning", type=int, default=0)
 args = ap.parse_args()
 cfg = q3.flagship_config()
 dec = Decoder(cfg, q3.synthetic_weights(cfg, 0), precision="bf16")
-from qwen3_tts_amd import _lib
 dec.set_tuning(args.tuning)
 pool = dec.open_streams(args.streams)
 ids = torch.tensor(pool.open_many(args.streams), dtype=torch.int32, device="cuda")
