@@ -216,3 +216,65 @@ def uninstall_decoder(model: Any) -> None:
         tok.decode = tok.reference_decode
         del tok.reference_decode
         tok.q3c_decoder = None
+
+
+class ModelCodeSource:
+    """A `server.CodeSource` made of a loaded Qwen3-TTS model: text -> the codes its talker LM generates.
+
+    The reference's calls return finished audio (`generate_voice_clone(...) -> (wavs, sr)`, reference server.py:245-251); the
+    one place the codes are visible from outside the `qwen-tts` package is where the model hands them to the tokenizer's
+    `decode`.  While a call of this object is in flight that `decode` is a recorder: it keeps the codes and returns silence
+    of the length the real decode would produce, so the model's own generation runs to its end, nothing is decoded twice,
+    and the server's streaming / batched decode gets the codes.  One generation at a time per model (the swap is a lock's
+    critical section), as the reference serves them.
+
+        src = ModelCodeSource(model, decoder.cfg)                       # after install_decoder(model)
+        engine = server.Engine(decoder, src)
+    """
+
+    def __init__(self, model: Any, cfg: DecoderConfig, method: str = "generate_voice_clone"):
+        import threading
+        self.model, self.cfg, self.method = model, cfg, method
+        self._tok, _ = find_speech_tokenizer(model)
+        self._lock = threading.Lock()
+
+    def _items(self, encoded: Any) -> list:
+        """The wrapper's input forms (a [T, Q] / [Q, T] matrix, a [B, ...] tensor, {"audio_codes": ...}, or a list of those)
+        -> list of [Q, T] int64 tensors on the host."""
+        Q = self.cfg.num_quantizers
+        if isinstance(encoded, dict):
+            encoded = encoded["audio_codes"]
+        if isinstance(encoded, (list, tuple)):
+            return [c for e in encoded for c in self._items(e)]
+        t = torch.as_tensor(encoded).detach().to("cpu", torch.int64)
+        if t.dim() == 3:
+            return [c for e in t for c in self._items(e)]
+        if t.dim() != 2 or Q not in t.shape:
+            raise ValueError(f"Expected codes with a dimension of {Q} code books, got {tuple(t.shape)}")
+        if t.shape[1] == Q:                                    # [T, Q], the item form of the wrapper (a square matrix reads as this)
+            return [t.t().contiguous()]
+        return [t]
+
+    def __call__(self, text: str, seed: Optional[int] = None, **kw: Any) -> torch.Tensor:
+        import numpy as np
+        seen: list = []
+
+        def recorder(encoded: Any, *a: Any, **k: Any):
+            items = self._items(encoded)
+            seen.extend(items)
+            return [np.zeros(self.cfg.chunked_output_length(int(c.shape[1])), dtype=np.float32) for c in items], self.cfg.sample_rate
+
+        with self._lock:
+            real = self._tok.decode
+            self._tok.decode = recorder
+            try:
+                if seed is not None:                        # as the reference seeds a request (server.py:348-351)
+                    torch.manual_seed(int(seed))
+                    if torch.cuda.is_available():
+                        torch.cuda.manual_seed(int(seed))
+                getattr(self.model, self.method)(text=text, **kw)
+            finally:
+                self._tok.decode = real
+        if not seen:
+            raise RuntimeError(f"{self.method} finished without handing any codes to the speech tokenizer's decode")
+        return seen[0] if len(seen) == 1 else torch.cat(seen, dim=1)

@@ -407,3 +407,33 @@ def hashed_code_source(cfg, frames_per_char: float = 0.9) -> CodeSource:
         return torch.randint(0, cfg.codebook_size, (cfg.num_quantizers, T), generator=g, dtype=torch.int64)
 
     return source
+
+
+def build_engine(manager=None, env: Optional[Dict[str, str]] = None) -> Engine:
+    """The engine of a real deployment: the model manager loads the default model from its LOCAL directory (models.py), installs
+    this decode into it, and the model's own generation becomes the code source (install.ModelCodeSource).  Environment, as the
+    reference's config.py reads it: TTS_DEVICE, TTS_DTYPE, TTS_DEFAULT_MODEL, TTS_USE_WARMUP, TTS_MODELS_DIR / MODEL_* paths;
+    plus TTS_STREAM_SLOTS (concurrent SSE requests, default 64) and TTS_CHUNK_FRAMES (frames per SSE audio event, default 25)."""
+    import os
+    from .install import ModelCodeSource
+    from .models import TTSModelManager
+    env = os.environ if env is None else env
+    slots, chunk = int(env.get("TTS_STREAM_SLOTS", "64")), int(env.get("TTS_CHUNK_FRAMES", "25"))
+    if manager is None:
+        manager = TTSModelManager(env=env)
+    key = manager.default_model if manager.default_model != "all" else "base"      # the voice-clone routes serve a base model
+    model = manager.get_model(key)
+    decoder = manager.get_decoder(key)
+    return Engine(decoder, ModelCodeSource(model, decoder.cfg), model_key=key, stream_slots=slots, chunk_frames=chunk)
+
+
+def main() -> None:
+    """`python -m qwen3_tts_amd.server`: what `python server.py` is for the reference (server.py:575-577; TTS_HOST / TTS_PORT as in
+    config.py:8-9)."""
+    import os
+    import uvicorn
+    uvicorn.run(create_app(build_engine()), host=os.getenv("TTS_HOST", "0.0.0.0"), port=int(os.getenv("TTS_PORT", "8000")))
+
+
+if __name__ == "__main__":
+    main()

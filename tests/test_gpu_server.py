@@ -263,3 +263,45 @@ def test_sse_full_pool_is_http_503_and_bad_chunks_stay_with_their_request():
         eng.streams.close_stream(b)
     finally:
         eng.close()
+
+
+def test_engine_built_from_the_model_manager_serves_the_models_own_codes(tmp_path):
+    """`server.build_engine`: the model manager loads a (stub) Qwen3TTSModel from a local directory, installs the real decoder
+    into it, and the model's own generation - codes handed to the tokenizer's decode - is the server's code source.  The
+    voice-clone route then answers with the oracle's decode of exactly those codes, and the model called directly (the
+    reference's own server path) returns the same samples through the installed decode."""
+    from fastapi.testclient import TestClient
+    from qwen3_tts_amd import models
+    from test_host_cpu import _StubDecoderModule, _StubTokenizer, _StubTTS
+    cfg = q3.tiny_config()
+    w = q3.synthetic_weights(cfg, seed=13)
+    src = server.hashed_code_source(cfg)
+
+    class Model(_StubTTS):
+        def __init__(self):
+            super().__init__(_StubTokenizer(_StubDecoderModule(cfg, {k: v.cuda() for k, v in w.items()}, "")))
+
+        def generate_voice_clone(self, text, **kw):
+            codes = src(text=text, seed=torch.initial_seed())                    # the "talker LM": seeded by the request
+            return self.model.speech_tokenizer.decode([{"audio_codes": codes.t().contiguous()}])       # [T, Q] items, as upstream
+
+    root = tmp_path / "models" / "Qwen3-TTS-12Hz-0.6B-Base"
+    root.mkdir(parents=True)
+    env = {"TTS_DEVICE": "cuda:0", "TTS_DTYPE": "float32", "TTS_STREAM_SLOTS": "2", "TTS_CHUNK_FRAMES": "10"}
+    mm = models.TTSModelManager(factory=lambda path, **kw: Model(), env=env, models_root=str(tmp_path / "models"))
+    eng = server.build_engine(mm, env)
+    try:
+        assert eng.pool.capacity == 2 and eng.chunk_frames == 10 and eng.get_loaded_models() == ["base_0.6b"]
+        client = TestClient(server.create_app(eng))
+        text = "A sentence for the stub model"
+        r = client.post("/tts/voice_clone", json={"text": text, "seed": 21, **REF})
+        assert r.status_code == 200, r.text
+        _close(_pcm_of_wav_file(r.content), _want_pcm(cfg, w, [src(text=text, seed=21)])[0])
+        # the reference's own path: the model called directly decodes through the installed MI355X decode
+        torch.manual_seed(21)
+        wavs, sr = mm.get_model("base_0.6b").generate_voice_clone(text=text)
+        assert sr == 24000
+        want = oracle.chunked_decode(cfg, w, src(text=text, seed=21)[None])[0, 0].numpy()
+        assert np.abs(wavs[0] - want).max() <= 1e-3
+    finally:
+        eng.close()

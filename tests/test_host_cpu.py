@@ -785,3 +785,40 @@ def test_launch_ordered_samples_reach_their_places_on_the_host():
     got = to_host_by_launch(flat, total, [int(dev_starts[20]), total], [None, None], dev_starts, host_starts, counts.astype(np.int64))
     assert np.array_equal(got, want)
     assert to_host_by_launch(torch.empty(0), 0, [], [], np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.int64)).shape == (0,)
+
+
+def test_model_code_source_takes_the_codes_at_the_decode_boundary():
+    """`install.ModelCodeSource`: the model's own generation runs with the tokenizer's decode replaced by a recorder; the codes
+    come back as [Q, T], the generation gets silence of the right length, and the real decode is back in place afterwards -
+    also when the generation raises."""
+    from qwen3_tts_amd import install
+    cfg = q3.tiny_config()
+    tok = _StubTokenizer(_StubDecoderModule(cfg, q3.synthetic_weights(cfg, seed=0), ""))
+    model = _StubTTS(tok)
+    calls = []
+
+    def generate_voice_clone(text, language="Auto", **kw):
+        g = torch.Generator().manual_seed(len(text))
+        codes = torch.randint(0, cfg.codebook_size, (len(text) + 3, cfg.num_quantizers), generator=g)      # [T, Q], as the wrapper takes them
+        wavs, sr = model.model.speech_tokenizer.decode([{"audio_codes": codes}])
+        calls.append((text, language, wavs[0].shape, sr, torch.initial_seed()))
+        if text == "boom":
+            raise RuntimeError("generation failed")
+        return wavs, sr
+
+    model.generate_voice_clone = generate_voice_clone
+    real = tok.decode
+    src = install.ModelCodeSource(model, cfg)
+    codes = src(text="hello", seed=7, language="Korean")
+    assert codes.shape == (cfg.num_quantizers, 8) and codes.dtype == torch.int64
+    g = torch.Generator().manual_seed(5)
+    assert torch.equal(codes, torch.randint(0, cfg.codebook_size, (8, cfg.num_quantizers), generator=g).t())
+    assert calls[0][:2] == ("hello", "Korean") and calls[0][2] == (cfg.chunked_output_length(8),) and calls[0][3] == cfg.sample_rate
+    assert calls[0][4] == 7                                        # the request's seed reached torch before the generation
+    assert tok.decode == real
+    with pytest.raises(RuntimeError, match="generation failed"):
+        src(text="boom")
+    assert tok.decode == real
+    model.generate_voice_clone = lambda text, **kw: ([np.zeros(4, np.float32)], 24000)      # never reaches the tokenizer
+    with pytest.raises(RuntimeError, match="without handing any codes"):
+        src(text="x")
