@@ -31,6 +31,11 @@ class _AliasFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
     def exec_module(self, module):
         pass
 
+    def get_code(self, name):
+        """`python -m qwen3_tts_amd.<submodule>`: runpy runs the real module's code as __main__."""
+        real = _REAL + name[len(_ALIAS):]
+        return sys.modules[real].__spec__.loader.get_code(real)
+
 
 if not any(isinstance(f, _AliasFinder) or type(f).__name__ == "_AliasFinder" for f in sys.meta_path):
     sys.meta_path.insert(0, _AliasFinder())

@@ -822,3 +822,13 @@ def test_model_code_source_takes_the_codes_at_the_decode_boundary():
     model.generate_voice_clone = lambda text, **kw: ([np.zeros(4, np.float32)], 24000)      # never reaches the tokenizer
     with pytest.raises(RuntimeError, match="without handing any codes"):
         src(text="x")
+
+
+def test_server_launcher_resolves_through_the_alias_and_refuses_a_missing_checkpoint():
+    """`python -m qwen3_tts_amd.server` (the reference's `python server.py`): runs the real module as __main__ through the
+    import alias, and without a local model directory stops before anything is fetched."""
+    import subprocess
+    env = {**os.environ, "TTS_MODELS_DIR": "/nonexistent-models", "PYTHONPATH": ROOT}
+    r = subprocess.run([sys.executable, "-m", "qwen3_tts_amd.server"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "FileNotFoundError" in r.stderr and "local directories only" in r.stderr
