@@ -232,11 +232,42 @@ class ModelCodeSource:
         engine = server.Engine(decoder, src)
     """
 
-    def __init__(self, model: Any, cfg: DecoderConfig, method: str = "generate_voice_clone"):
+    def __init__(self, model: Any, cfg: DecoderConfig, method: str = "generate_voice_clone", prompt_cache: int = 16):
         import threading
         self.model, self.cfg, self.method = model, cfg, method
         self._tok, _ = find_speech_tokenizer(model)
         self._lock = threading.Lock()
+        self._prompts: Dict[tuple, Any] = {}         # (ref_audio, ref_text, x_vector_only_mode) -> voice clone prompt
+        self._prompt_cap = int(prompt_cache)
+
+    def _with_prompt(self, kw: Dict[str, Any]) -> Dict[str, Any]:
+        """The reference computes the voice-clone prompt (speaker embedding, reference codes) ONCE per request and passes it to
+        every sentence's generation (`create_voice_clone_prompt`, then `voice_clone_prompt=` with `non_streaming_mode=True`,
+        server.py:228-251, 298-372), falling back to the direct `ref_audio` call when that fails.  Here the prompt is kept
+        per (reference audio, transcript, mode) for the most recent few, so the sentences of a request - and later requests
+        with the same voice - share it.  Models without `create_voice_clone_prompt`, calls without a `ref_audio` string, and
+        any failure take the direct call."""
+        make = getattr(self.model, "create_voice_clone_prompt", None)
+        ref = kw.get("ref_audio")
+        if self.method != "generate_voice_clone" or make is None or not isinstance(ref, str) or "voice_clone_prompt" in kw:
+            return kw
+        key = (ref, kw.get("ref_text"), bool(kw.get("x_vector_only_mode", True)))
+        prompt = self._prompts.pop(key, None)
+        if prompt is None:
+            try:
+                prompt = make(ref_audio=ref, ref_text=kw.get("ref_text"), x_vector_only_mode=key[2])
+                item = prompt[0] if prompt else None
+                if item is None or getattr(item, "ref_spk_embedding", None) is None:
+                    raise ValueError("voice clone prompt is empty or has no speaker embedding")
+            except Exception as e:                              # as the reference: "falling back to direct ref_audio mode"
+                print(f"[ModelCodeSource] voice clone prompt failed ({e}); falling back to the direct ref_audio call")
+                return kw
+            while len(self._prompts) >= self._prompt_cap:
+                self._prompts.pop(next(iter(self._prompts)))
+        self._prompts[key] = prompt                             # (re)inserted last: most recently used
+        out = {k: v for k, v in kw.items() if k not in ("ref_audio", "ref_text", "x_vector_only_mode")}
+        out.update(voice_clone_prompt=prompt, non_streaming_mode=True)
+        return out
 
     def _items(self, encoded: Any) -> list:
         """The wrapper's input forms (a [T, Q] / [Q, T] matrix, a [B, ...] tensor, {"audio_codes": ...}, or a list of those)
@@ -272,7 +303,7 @@ class ModelCodeSource:
                     torch.manual_seed(int(seed))
                     if torch.cuda.is_available():
                         torch.cuda.manual_seed(int(seed))
-                getattr(self.model, self.method)(text=text, **kw)
+                getattr(self.model, self.method)(text=text, **self._with_prompt(kw))
             finally:
                 self._tok.decode = real
         if not seen:

@@ -832,3 +832,40 @@ def test_server_launcher_resolves_through_the_alias_and_refuses_a_missing_checkp
     r = subprocess.run([sys.executable, "-m", "qwen3_tts_amd.server"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
     assert "FileNotFoundError" in r.stderr and "local directories only" in r.stderr
+
+
+def test_model_code_source_precomputes_the_voice_clone_prompt_as_the_reference_does():
+    """One `create_voice_clone_prompt` per (reference audio, transcript, mode), reused by later sentences and requests, passed
+    as `voice_clone_prompt=` with `non_streaming_mode=True` (reference server.py:228-251); a failing prompt falls back to the
+    direct ref_audio call."""
+    import types
+    from qwen3_tts_amd import install
+    cfg = q3.tiny_config()
+    tok = _StubTokenizer(_StubDecoderModule(cfg, q3.synthetic_weights(cfg, seed=0), ""))
+    model = _StubTTS(tok)
+    made, calls = [], []
+
+    def create_voice_clone_prompt(ref_audio, ref_text, x_vector_only_mode):
+        made.append((ref_audio, ref_text, x_vector_only_mode))
+        if ref_audio == "broken.wav":
+            raise OSError("cannot read")
+        return [types.SimpleNamespace(ref_spk_embedding=torch.ones(4), x_vector_only_mode=x_vector_only_mode, icl_mode=False, ref_code=None)]
+
+    def generate_voice_clone(text, **kw):
+        calls.append(kw)
+        return model.model.speech_tokenizer.decode([torch.zeros((5, cfg.num_quantizers), dtype=torch.int64)])
+
+    model.create_voice_clone_prompt, model.generate_voice_clone = create_voice_clone_prompt, generate_voice_clone
+    src = install.ModelCodeSource(model, cfg, prompt_cache=2)
+    kw = dict(language="Korean", ref_audio="a.wav", ref_text="hi", x_vector_only_mode=True, max_new_tokens=64)
+    for _ in range(3):
+        assert src(text="one sentence", **kw).shape == (cfg.num_quantizers, 5)
+    assert made == [("a.wav", "hi", True)]                         # computed once, shared by the three generations
+    assert all("ref_audio" not in c and c["non_streaming_mode"] is True and c["voice_clone_prompt"][0].icl_mode is False
+               and c["language"] == "Korean" and c["max_new_tokens"] == 64 for c in calls)
+    src(text="x", **{**kw, "ref_audio": "broken.wav"})             # prompt fails: the direct call, as the reference falls back
+    assert calls[-1]["ref_audio"] == "broken.wav" and "voice_clone_prompt" not in calls[-1]
+    src(text="x", **{**kw, "ref_audio": "b.wav"})
+    src(text="x", **{**kw, "ref_audio": "c.wav"})                  # cache of two: a.wav is the least recently used and goes
+    src(text="x", **kw)
+    assert [m[0] for m in made] == ["a.wav", "broken.wav", "b.wav", "c.wav", "a.wav"]
