@@ -13,7 +13,13 @@ Besides the contract fields the line carries
   roofline      the dominant kernel (by summed time): algorithmic FLOPs of its launches / their summed duration,
                 both measured in this run by HIP events on the launch stream, against the dense bf16 MFMA peak;
   cpu_baseline  the CPU restatement of the decode (oracle/, fp32 torch) timed on this host's cores on a bounded
-                sample (N = 1 only).
+                sample (N = 1 only);
+  kernels       the eight kernels with the most time: launches, ms per step, achieved TFLOP/s or GB/s of algorithmic work;
+  config        beside the workload: the rate with the samples copied to the host (`value_incl_d2h`) and through the
+                `decode` wrapper with numpy results (`value_decode_wrapper`), the step with every context row computed;
+  streaming, mixed_lengths, long_form   (N = 1 only) short records of BASELINE.json configs[2..4], measured after and
+                outside the timed region; `--workload stream | mixed | longform | encode` are the full measurements,
+                `--workload stream --sweep 256,1024,...` the capacity curve.
 """
 from __future__ import annotations
 
